@@ -1,0 +1,176 @@
+/*
+ * ecckd_hip.h -- C ABI of librte_ecckd_hip.so: the MI355X (gfx950) implementation of the
+ * rte-ecckd hot path (ecCKD gas optics + RTE LW/SW flux solvers).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain pointers and
+ * sizes, and is what a Fortran `iso_c_binding` interface block (or ctypes) binds; the
+ * reference-side binding is shown in INTEGRATION.md and shipped in
+ * rte-ecckd_amd/fortran/gas_optics_ecckd.F90.  Citations `file:line` are into the reference
+ * repository (earth-system-radiation/rte-ecckd).
+ *
+ * Conventions
+ *   - All arrays are contiguous, Fortran column-major, column index fastest, fp64:
+ *     plev(ncol,nlay+1), tlay(ncol,nlay), tau(ncol,nlay,ngpt), flux(ncol,nlay+1) ...
+ *   - `memspace` says where the DATA arrays live: ECCKD_HOST (the library stages them
+ *     through device buffers it owns, and synchronises before returning) or ECCKD_DEVICE
+ *     (pointers are device pointers on the model's GPU; the call is asynchronous on
+ *     `stream`).  Small descriptor arrays (gas names, pointer tables, strides, Ds/weights,
+ *     band2gpt) are always host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Return value: 0 on success, non-zero on error; the message (same texts as the
+ *     reference's character(len=128) results, src/gas_optics_ecckd.f90:331,393,442) is
+ *     returned by ecckd_last_error().  There is no CPU fallback: without a usable GPU every
+ *     compute entry point fails with an error.
+ *   - Re-entrancy: a model is immutable after ecckd_model_finalize (the reference's
+ *     `intent(in) :: this`, :385,:434); concurrent calls on different streams are safe in
+ *     ECCKD_DEVICE mode.  ECCKD_HOST mode uses a per-model staging arena and is serialised
+ *     by an internal mutex.
+ */
+#ifndef ECCKD_HIP_H
+#define ECCKD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECCKD_HOST 0
+#define ECCKD_DEVICE 1
+
+/* concentration_dependence_code values, src/gas_optics_ecckd.f90:54-57 */
+#define ECCKD_NONE 0
+#define ECCKD_LINEAR 1
+#define ECCKD_LOOK_UP_TABLE 2
+#define ECCKD_RELATIVE_LINEAR 3
+
+#define ECCKD_MAX_GASES 16   /* src/gas_optics_ecckd.f90:24-25 */
+#define ECCKD_NAME_LEN 32    /* character(len=32) gas names, :25 */
+
+typedef struct ecckd_model ecckd_model_t; /* replaces type(ty_gas_optics_ecckd), :23-48 */
+
+/* Message of the most recent failing call on this thread (never NULL). */
+const char *ecckd_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Model construction.  Two routes, both ending in an immutable device-resident model:
+ *   (1) ecckd_model_load  = load_and_init, example/rfmip-rad-irf/mo_load_coefficients.F90:19-146
+ *       (own netCDF-3 classic reader; no libnetcdf needed);
+ *   (2) ecckd_model_begin / _set_* / _add_gas / _finalize = filling the public members of
+ *       ty_gas_optics_ecckd directly (src/gas_optics_ecckd.f90:24-36), for hosts that
+ *       already hold the tables.
+ * --------------------------------------------------------------------------------------- */
+
+/* load_and_init(ecckd, filename, available_gases): available_gases is accepted and ignored
+ * by the reference (mo_load_coefficients.F90:19,23) and therefore has no parameter here. */
+int ecckd_model_load(const char *filename, int device, ecckd_model_t **model);
+
+/* log_pressure(np) [ln Pa] (:27), temperature(np,nt) [K] (:34); ng = size(gpoint_fraction,2)
+ * (:26, only its extent is ever used, :110). */
+int ecckd_model_begin(int ng, int np, int nt, const double *log_pressure,
+                      const double *temperature, ecckd_model_t **model);
+/* planck_function(ng,ntp) (:30), temperature_planck(ntp) (:35)  -> source_is_internal */
+int ecckd_model_set_planck(ecckd_model_t *model, int ntp, const double *temperature_planck,
+                           const double *planck_function);
+/* solar_irradiance(ng) (:33), rayleigh_molar_scattering_coeff(ng) (:31) -> source_is_external */
+int ecckd_model_set_solar(ecckd_model_t *model, const double *solar_irradiance,
+                          const double *rayleigh_molar_scattering_coeff);
+/* ty_optical_props%init(band_lims_wvn(2,nband), band2gpt(2,nband)) as called at
+ * mo_load_coefficients.F90:74; band2gpt is 1-based, inclusive. */
+int ecckd_model_set_bands(ecckd_model_t *model, int nband, const double *band_lims_wvn,
+                          const int *band2gpt);
+/* One AbsorptionTable (:13-19) + its name (:25).  coefficient is (ng,np,nt,nv); nv = 1 and
+ * mole_fraction = NULL unless code == ECCKD_LOOK_UP_TABLE. */
+int ecckd_model_add_gas(ecckd_model_t *model, const char *name, int concentration_dependence_code,
+                        int composite_only, int nv, const double *mole_fraction,
+                        double reference_mole_fraction, const double *coefficient);
+/* Upload the tables to GPU `device` (HIP ordinal) and freeze the model. */
+int ecckd_model_finalize(ecckd_model_t *model, int device);
+void ecckd_model_destroy(ecckd_model_t *model);
+
+/* Type-bound getters of ty_gas_optics_ecckd (:38-45, :477-553) and of its parent
+ * (get_ngpt/get_nband, used at ecckd_rfmip_sw.F90:78-79). */
+int ecckd_model_get_ngpt(const ecckd_model_t *model);
+int ecckd_model_get_nband(const ecckd_model_t *model);
+int ecckd_model_get_ngas(const ecckd_model_t *model);                       /* :477-483 */
+/* name is ECCKD_NAME_LEN bytes, NUL-terminated; index is 0-based. */
+int ecckd_model_get_gas_name(const ecckd_model_t *model, int index, char *name);   /* :507-513 */
+int ecckd_model_source_is_internal(const ecckd_model_t *model);             /* :487-493 */
+int ecckd_model_source_is_external(const ecckd_model_t *model);             /* :497-503 */
+double ecckd_model_get_press_min(const ecckd_model_t *model);               /* :517-523 */
+double ecckd_model_get_press_max(const ecckd_model_t *model);               /* :527-533 */
+double ecckd_model_get_temp_min(const ecckd_model_t *model);                /* :537-543 */
+double ecckd_model_get_temp_max(const ecckd_model_t *model);                /* :547-553 */
+double ecckd_model_get_total_solar_irradiance(const ecckd_model_t *model);  /* :36 */
+/* band2gpt(2,nband), 1-based inclusive; band_lims_wvn(2,nband) */
+int ecckd_model_get_band2gpt(const ecckd_model_t *model, int *band2gpt);
+int ecckd_model_get_band_lims_wvn(const ecckd_model_t *model, double *band_lims_wvn);
+int ecckd_model_get_device(const ecckd_model_t *model);
+
+/* ---------------------------------------------------------------------------------------
+ * gas_optics.  `gas_desc` (type(ty_gas_concs)) crosses the boundary as:
+ *   ngas          gas_desc%get_num_gases()                         (:340)
+ *   gas_names     ngas records of ECCKD_NAME_LEN chars, blank- or NUL-padded, in
+ *                 gas_desc%get_gas_names() order                  (:342; order matters: :348)
+ *   vmr[j]        data pointer of gas j in `memspace`, or NULL to use vmr_scalar[j]
+ *   vmr_col_stride[j], vmr_lay_stride[j]
+ *                 element strides so that get_vmr's broadcast (:351) is
+ *                 vmr(i,l) = vmr[j][i*col_stride + l*lay_stride]:
+ *                 (1,ncol) for a (ncol,nlay) array, (0,1) for a profile, (1,0) per column
+ *   vmr_scalar[j] value used when vmr[j] == NULL (a ty_gas_concs scalar)
+ * Gases unknown to the model are skipped, composite-only gases contribute the composite
+ * table once (:358-373).
+ * --------------------------------------------------------------------------------------- */
+
+/* gas_optics_int (:381-426): tau, lay_source, lev_source_inc, lev_source_dec are
+ * (ncol,nlay,ngpt), sfc_source is (ncol,ngpt).  `play` and `col_dry` are unused by the
+ * reference (:386,:394) and have no parameter.  tlev == NULL reproduces the reference:
+ * tau, lay_source and sfc_source are written, then the call fails with
+ * "tlev is required for ecckd" (:414-417).  Unlike the reference (:266-269 via :407) the
+ * caller's lay_source is never reallocated. */
+int ecckd_gas_optics_lw(const ecckd_model_t *model, int ncol, int nlay, const double *plev,
+                        const double *tlay, const double *tsfc, const double *tlev, int ngas,
+                        const char *gas_names, const double *const *vmr,
+                        const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                        const double *vmr_scalar, double *tau, double *lay_source,
+                        double *lev_source_inc, double *lev_source_dec, double *sfc_source,
+                        int memspace, void *stream);
+
+/* gas_optics_ext (:431-473): tau, ssa, g are (ncol,nlay,ngpt); toa_src is (ncol,ngpt).
+ * ssa == NULL or g == NULL stands for an optical_props that is not ty_optical_props_2str:
+ * tau (gas + Rayleigh) is written and the call fails with
+ * "shortwave must use ty_optical_props_2str" (:461-463). */
+int ecckd_gas_optics_sw(const ecckd_model_t *model, int ncol, int nlay, const double *plev,
+                        const double *tlay, int ngas, const char *gas_names,
+                        const double *const *vmr, const long long *vmr_col_stride,
+                        const long long *vmr_lay_stride, const double *vmr_scalar, double *tau,
+                        double *ssa, double *g, double *toa_src, int memspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RTE solvers (RTE-RRTMGP rte_lw / rte_sw as called at ecckd_rfmip_lw.F90:130-135 and
+ * ecckd_rfmip_sw.F90:148-154) with the broadband g-point reduction
+ * (ty_fluxes_broadband%reduce) fused in.  flux_up, flux_dn are (ncol,nlay+1).
+ * --------------------------------------------------------------------------------------- */
+
+/* No-scattering LW with Gauss-Jacobi quadrature, n_gauss_angles in 1..4.  sfc_emis is
+ * (nband,ncol) as in rte_lw; band2gpt(2,nband) (1-based, inclusive) expands it to g-points
+ * (ecckd_rfmip_lw.F90:112-116).  ngpt <= 256. */
+int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                 const double *tau, const double *lay_source, const double *lev_source_inc,
+                 const double *lev_source_dec, const double *sfc_source, int nband,
+                 const int *band2gpt, const double *sfc_emis, double *flux_up, double *flux_dn,
+                 int memspace, void *stream);
+
+/* Two-stream + adding SW.  mu0(ncol), toa_flux(ncol,ngpt), sfc_alb_dir/dif(nband,ncol).
+ * flux_dn includes the direct beam; flux_dir (ncol,nlay+1) may be NULL. */
+int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
+                 const double *ssa, const double *g, const double *mu0, const double *toa_flux,
+                 int nband, const int *band2gpt, const double *sfc_alb_dir,
+                 const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
+                 int memspace, void *stream);
+
+/* Library / build identification ("gfx950", compile flags); never NULL. */
+const char *ecckd_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,520 @@
+"""rte-ecckd hot path for MI355X -- Python host side.
+
+This package is a thin mirror of the reference's Fortran interface on top of the C ABI in
+``include/ecckd_hip.h`` (``librte_ecckd_hip.so``, hand-written HIP for gfx950):
+
+* :class:`GasOpticsEcckd`  <-> ``type(ty_gas_optics_ecckd)`` (src/gas_optics_ecckd.f90:23-48)
+  with ``load()`` (= ``load_and_init``, example/rfmip-rad-irf/mo_load_coefficients.F90:19) and
+  the generic ``gas_optics()`` (LW: ``gas_optics_int`` :381, SW: ``gas_optics_ext`` :431);
+* :class:`GasConcs`, :class:`OpticalProps1scl`, :class:`OpticalProps2str`,
+  :class:`SourceFuncLW`, :class:`FluxesBroadband` <-> the RTE-RRTMGP types the reference
+  passes around (only the members it touches);
+* :func:`rte_lw`, :func:`rte_sw` <-> RTE-RRTMGP's solvers as called at
+  ecckd_rfmip_lw.F90:130-135 and ecckd_rfmip_sw.F90:148-154.
+
+Error behaviour follows the reference: the entry points return a message string, empty on
+success.  Arrays are numpy (host: staged through the GPU by the library) or torch CUDA tensors
+(device resident, asynchronous on the current stream); either way C-ordered with the REVERSE
+of the Fortran shape, i.e. the reference's column-major memory: ``tau`` is
+``(ngpt, nlay, ncol)``, ``plev`` is ``(nlay+1, ncol)``, fluxes are ``(nlay+1, ncol)``.
+
+There is no CPU fallback anywhere in this package: without the HIP library and a GPU every
+compute call raises / returns an error.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "librte_ecckd_hip.so")
+HOST, DEVICE = 0, 1
+NAME_LEN = 32
+
+_SOURCES = ["kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_sw.hip",
+            "capi.cpp", "model.cpp", "cdf1.cpp"]
+_HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    deps = srcs + [os.path.join(_CSRC, h) for h in _HEADERS]
+    if not force and os.path.exists(LIB_PATH):
+        t = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    """Load librte_ecckd_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("librte_ecckd_hip.so is missing: run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (there is no CPU fallback)")
+    try:  # share torch's HIP runtime when torch is around (it must be loaded first)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.ecckd_last_error.restype = C.c_char_p
+    L.ecckd_build_info.restype = C.c_char_p
+    for f in ("press_min", "press_max", "temp_min", "temp_max", "total_solar_irradiance"):
+        getattr(L, "ecckd_model_get_" + f).restype = C.c_double
+        getattr(L, "ecckd_model_get_" + f).argtypes = [C.c_void_p]
+    for f in ("ngpt", "nband", "ngas", "device"):
+        getattr(L, "ecckd_model_get_" + f).argtypes = [C.c_void_p]
+    L.ecckd_model_source_is_internal.argtypes = [C.c_void_p]
+    L.ecckd_model_source_is_external.argtypes = [C.c_void_p]
+    L.ecckd_model_destroy.argtypes = [C.c_void_p]
+    L.ecckd_model_destroy.restype = None
+    L.ecckd_model_add_gas.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_double, C.c_void_p]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().ecckd_last_error().decode()
+
+
+# ------------------------------------------------------------------------------------------
+# array plumbing: numpy (host) or torch.cuda tensors (device)
+# ------------------------------------------------------------------------------------------
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _space_of(arrays):
+    dev = [a for a in arrays if a is not None and _is_torch(a) and a.is_cuda]
+    if not dev:
+        return HOST
+    for a in arrays:
+        if a is not None and not (_is_torch(a) and a.is_cuda):
+            raise TypeError("mixing host and device arrays in one call")
+    return DEVICE
+
+
+def _ptr(a, shape=None, what="array"):
+    """Data pointer of a C-contiguous float64 array (numpy or torch)."""
+    if a is None:
+        return None
+    if _is_torch(a):
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise TypeError(what + ": need a contiguous float64 tensor")
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError("%s: shape %s, expected %s" % (what, tuple(a.shape), tuple(shape)))
+        return C.c_void_p(a.data_ptr())
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise TypeError(what + ": need a C-contiguous float64 ndarray")
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s: shape %s, expected %s" % (what, a.shape, tuple(shape)))
+    return C.c_void_p(a.ctypes.data)
+
+
+def _stream(space):
+    if space == DEVICE:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def _empty_like_space(shape, like):
+    if _is_torch(like):
+        import torch
+        return torch.empty(shape, dtype=torch.float64, device=like.device)
+    return np.empty(shape, dtype=np.float64)
+
+
+# ------------------------------------------------------------------------------------------
+# RTE-RRTMGP data types, as far as the reference touches them
+# ------------------------------------------------------------------------------------------
+class GasConcs:
+    """``ty_gas_concs``: init / set_vmr / get_vmr / get_gas_names / get_num_gases
+    (used at src/gas_optics_ecckd.f90:340-351 and mo_rfmip_io.F90:202-259)."""
+
+    def __init__(self, gas_names=()):
+        self.init(gas_names)
+
+    def init(self, gas_names):
+        names = [n.strip().lower() for n in gas_names]
+        if len(set(names)) != len(names):
+            return "ty_gas_concs%init: duplicate gas names aren't allowed"
+        if any(len(n) == 0 for n in names):
+            return "ty_gas_concs%init: must provide non-empty gas names"
+        self._names = names
+        self._conc = {}
+        return ""
+
+    def set_vmr(self, gas, w):
+        """w: scalar, profile ``(nlay,)``, or full ``(nlay, ncol)`` [Fortran (ncol,nlay)]."""
+        gas = gas.strip().lower()
+        if gas not in self._names:
+            return "ty_gas_concs%set_vmr: trying to set " + gas + " but name not provided at initialization"
+        if np.isscalar(w):
+            if w < 0 or w > 1:
+                return "ty_gas_concs%set_vmr: concentrations should be >= 0, <= 1"
+            self._conc[gas] = float(w)
+        else:
+            if w.ndim not in (1, 2):
+                return "ty_gas_concs%set_vmr: need a scalar, (nlay) or (ncol,nlay) array"
+            self._conc[gas] = w
+        return ""
+
+    def set_vmr_column(self, gas, w):
+        """Extension of the C ABI (per-column value, broadcast over layers)."""
+        gas = gas.strip().lower()
+        if gas not in self._names:
+            return "ty_gas_concs%set_vmr: trying to set " + gas + " but name not provided at initialization"
+        self._conc[gas] = ("column", w)
+        return ""
+
+    def get_num_gases(self):
+        return len(self._names)
+
+    def get_gas_names(self):
+        return list(self._names)
+
+    def entries(self, ncol, nlay):
+        """[(name, array-or-None, col_stride, lay_stride, scalar)] in gas order; raises KeyError
+        with the ty_gas_concs%get_vmr message for a gas that was never set."""
+        out = []
+        for n in self._names:
+            if n not in self._conc:
+                raise KeyError("ty_gas_concs%get_vmr; gas " + n + " not found")
+            w = self._conc[n]
+            if isinstance(w, float):
+                out.append((n, None, 0, 0, w))
+            elif isinstance(w, tuple):
+                if tuple(w[1].shape) != (ncol,):
+                    raise KeyError("ty_gas_concs%get_vmr; gas " + n + " array is inconsistent with ncol")
+                out.append((n, w[1], 1, 0, 0.0))
+            elif w.ndim == 1:
+                if w.shape[0] != nlay:
+                    raise KeyError("ty_gas_concs%get_vmr; gas " + n + " array is inconsistent with nlay")
+                out.append((n, w, 0, 1, 0.0))
+            else:
+                if tuple(w.shape) != (nlay, ncol):
+                    raise KeyError("ty_gas_concs%get_vmr; gas " + n + " array is inconsistent with ncol/nlay")
+                out.append((n, w, 1, ncol, 0.0))
+        return out
+
+
+class OpticalProps1scl:
+    """``ty_optical_props_1scl``: tau(ncol,nlay,ngpt) (+ band structure of the parent)."""
+
+    def __init__(self):
+        self.tau = None
+        self.band2gpt = None
+
+    def alloc_1scl(self, ncol, nlay, spectral_desc, like=None):
+        self.band2gpt = spectral_desc.get_band2gpt()
+        ng = spectral_desc.get_ngpt()
+        self.tau = _empty_like_space((ng, nlay, ncol), like if like is not None else np.empty(0))
+        return ""
+
+    def get_ngpt(self):
+        return self.tau.shape[0]
+
+
+class OpticalProps2str(OpticalProps1scl):
+    """``ty_optical_props_2str``: tau, ssa, g."""
+
+    def __init__(self):
+        super().__init__()
+        self.ssa = None
+        self.g = None
+
+    def alloc_2str(self, ncol, nlay, spectral_desc, like=None):
+        self.alloc_1scl(ncol, nlay, spectral_desc, like)
+        self.ssa = _empty_like_space(tuple(self.tau.shape), self.tau)
+        self.g = _empty_like_space(tuple(self.tau.shape), self.tau)
+        return ""
+
+
+class SourceFuncLW:
+    """``ty_source_func_lw``: lay_source, lev_source_inc, lev_source_dec, sfc_source."""
+
+    def __init__(self):
+        self.lay_source = self.lev_source_inc = self.lev_source_dec = self.sfc_source = None
+
+    def alloc(self, ncol, nlay, spectral_desc, like=None):
+        ng = spectral_desc.get_ngpt()
+        like = like if like is not None else np.empty(0)
+        self.lay_source = _empty_like_space((ng, nlay, ncol), like)
+        self.lev_source_inc = _empty_like_space((ng, nlay, ncol), like)
+        self.lev_source_dec = _empty_like_space((ng, nlay, ncol), like)
+        self.sfc_source = _empty_like_space((ng, ncol), like)
+        return ""
+
+
+class FluxesBroadband:
+    """``ty_fluxes_broadband``: flux_up, flux_dn (ncol,nlay+1) [+ flux_dn_dir]."""
+
+    def __init__(self, flux_up=None, flux_dn=None, flux_dn_dir=None):
+        self.flux_up, self.flux_dn, self.flux_dn_dir = flux_up, flux_dn, flux_dn_dir
+
+
+# ------------------------------------------------------------------------------------------
+# ty_gas_optics_ecckd
+# ------------------------------------------------------------------------------------------
+class GasOpticsEcckd:
+    """``type(ty_gas_optics_ecckd)`` backed by a device-resident model handle."""
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.finalize()
+        except Exception:
+            pass
+
+    def finalize(self):
+        if self._h:
+            lib().ecckd_model_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    # -- construction ---------------------------------------------------------------
+    def load(self, filename, available_gases=None, device=0):
+        """``load_and_init(ecckd, filename, available_gases)``; ``available_gases`` is accepted
+        and ignored exactly as in the reference (mo_load_coefficients.F90:19,23)."""
+        self.finalize()
+        h = C.c_void_p(None)
+        if lib().ecckd_model_load(os.fsencode(filename), int(device), C.byref(h)):
+            return last_error()
+        self._h = h
+        return ""
+
+    def init_from_tables(self, log_pressure, temperature, gases, planck=None, solar=None, bands=None,
+                         device=0):
+        """Fill the public members directly (src/gas_optics_ecckd.f90:24-36).  ``temperature`` is
+        ``(nt,np)``, tables ``(nv,nt,np,ng)``; ``planck=(temperature_planck, planck_function(ntp,ng))``;
+        ``solar=(solar_irradiance, rayleigh)``; ``bands=(band_lims_wvn(nband,2), band2gpt(nband,2))``;
+        ``gases`` = list of dicts(name, code, composite_only, mole_fraction, reference_mole_fraction,
+        coefficient)."""
+        self.finalize()
+        L = lib()
+        f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        lp, T = f8(log_pressure), f8(temperature)
+        ng = gases[0]["coefficient"].shape[-1]
+        h = C.c_void_p(None)
+        if L.ecckd_model_begin(ng, lp.shape[0], T.shape[0], _ptr(lp), _ptr(T), C.byref(h)):
+            return last_error()
+        try:
+            if planck is not None:
+                tp, pf = f8(planck[0]), f8(planck[1])
+                if L.ecckd_model_set_planck(h, tp.shape[0], _ptr(tp), _ptr(pf)):
+                    raise RuntimeError(last_error())
+            if solar is not None:
+                si, ray = f8(solar[0]), f8(solar[1])
+                if L.ecckd_model_set_solar(h, _ptr(si), _ptr(ray)):
+                    raise RuntimeError(last_error())
+            if bands is not None:
+                lims = f8(bands[0])
+                b2g = np.ascontiguousarray(bands[1], dtype=np.int32)
+                if L.ecckd_model_set_bands(h, b2g.shape[0], _ptr(lims), C.c_void_p(b2g.ctypes.data)):
+                    raise RuntimeError(last_error())
+            for g in gases:
+                coef = f8(g["coefficient"])
+                mf = g.get("mole_fraction")
+                mf = None if mf is None else f8(mf)
+                if L.ecckd_model_add_gas(h, g["name"].encode(), int(g["code"]), int(g.get("composite_only", 0)),
+                                         coef.shape[0] if coef.ndim == 4 else 1, _ptr(mf),
+                                         float(g.get("reference_mole_fraction", 0.0)), _ptr(coef)):
+                    raise RuntimeError(last_error())
+            if L.ecckd_model_finalize(h, int(device)):
+                raise RuntimeError(last_error())
+        except RuntimeError as e:
+            L.ecckd_model_destroy(h)
+            return str(e)
+        self._h = h
+        return ""
+
+    # -- type-bound getters (src/gas_optics_ecckd.f90:477-553 + parent) -----------------
+    def _need(self):
+        if not self._h:
+            raise RuntimeError("ty_gas_optics_ecckd: not loaded")
+        return self._h
+
+    def get_ngpt(self):
+        return lib().ecckd_model_get_ngpt(self._need())
+
+    def get_nband(self):
+        return lib().ecckd_model_get_nband(self._need())
+
+    def get_ngas(self):
+        return lib().ecckd_model_get_ngas(self._need())
+
+    def get_gases(self):
+        out = []
+        buf = C.create_string_buffer(NAME_LEN)
+        for i in range(self.get_ngas()):
+            lib().ecckd_model_get_gas_name(self._need(), i, buf)
+            out.append(buf.value.decode())
+        return out
+
+    def source_is_internal(self):
+        return bool(lib().ecckd_model_source_is_internal(self._need()))
+
+    def source_is_external(self):
+        return bool(lib().ecckd_model_source_is_external(self._need()))
+
+    def get_press_min(self):
+        return lib().ecckd_model_get_press_min(self._need())
+
+    def get_press_max(self):
+        return lib().ecckd_model_get_press_max(self._need())
+
+    def get_temp_min(self):
+        return lib().ecckd_model_get_temp_min(self._need())
+
+    def get_temp_max(self):
+        return lib().ecckd_model_get_temp_max(self._need())
+
+    def get_total_solar_irradiance(self):
+        return lib().ecckd_model_get_total_solar_irradiance(self._need())
+
+    def get_band2gpt(self):
+        b = np.zeros((self.get_nband(), 2), dtype=np.int32)
+        lib().ecckd_model_get_band2gpt(self._need(), C.c_void_p(b.ctypes.data))
+        return b
+
+    def get_band_lims_wavenumber(self):
+        b = np.zeros((self.get_nband(), 2), dtype=np.float64)
+        lib().ecckd_model_get_band_lims_wvn(self._need(), C.c_void_p(b.ctypes.data))
+        return b
+
+    def get_device(self):
+        return lib().ecckd_model_get_device(self._need())
+
+    # -- gas_optics ---------------------------------------------------------------------
+    def _gas_args(self, gas_desc, ncol, nlay, space):
+        ent = gas_desc.entries(ncol, nlay)
+        n = len(ent)
+        names = b"".join(e[0].encode().ljust(NAME_LEN, b" ") for e in ent)
+        keep = []
+        ptrs = (C.c_void_p * max(n, 1))()
+        for i, e in enumerate(ent):
+            if e[1] is None:
+                ptrs[i] = None
+            else:
+                if (_is_torch(e[1]) and e[1].is_cuda) != (space == DEVICE):
+                    raise TypeError("gas " + e[0] + ": vmr array is not in the same memory space as the inputs")
+                p = _ptr(e[1], what="vmr of " + e[0])
+                keep.append(e[1])
+                ptrs[i] = p.value
+        cs = (C.c_longlong * max(n, 1))(*[e[2] for e in ent])
+        ls = (C.c_longlong * max(n, 1))(*[e[3] for e in ent])
+        sc = (C.c_double * max(n, 1))(*[e[4] for e in ent])
+        return n, names, ptrs, cs, ls, sc, keep
+
+    def gas_optics(self, play, plev, tlay, *args, **kw):
+        """Generic ``gas_optics``: ``(play, plev, tlay, tsfc, gas_desc, optical_props, sources,
+        col_dry=None, tlev=None)`` -> gas_optics_int; ``(play, plev, tlay, gas_desc, optical_props,
+        toa_src, col_dry=None)`` -> gas_optics_ext.  Returns the error message ('' = success)."""
+        if len(args) >= 1 and isinstance(args[0], GasConcs):
+            return self.gas_optics_ext(play, plev, tlay, *args, **kw)
+        return self.gas_optics_int(play, plev, tlay, *args, **kw)
+
+    def gas_optics_int(self, play, plev, tlay, tsfc, gas_desc, optical_props, sources, col_dry=None,
+                       tlev=None):
+        nlay, ncol = tlay.shape
+        ng = self.get_ngpt()
+        try:
+            space = _space_of([plev, tlay, tsfc, tlev, optical_props.tau, sources.lay_source])
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+        except KeyError as e:
+            return str(e.args[0])
+        rc = lib().ecckd_gas_optics_lw(
+            self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"), _ptr(tlay, (nlay, ncol), "tlay"),
+            _ptr(tsfc, (ncol,), "tsfc"), _ptr(tlev, (nlay + 1, ncol), "tlev"), n, names, ptrs, cs, ls, sc,
+            _ptr(optical_props.tau, (ng, nlay, ncol), "tau"),
+            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
+        return last_error() if rc else ""
+
+    def gas_optics_ext(self, play, plev, tlay, gas_desc, optical_props, toa_src, col_dry=None):
+        nlay, ncol = tlay.shape
+        ng = self.get_ngpt()
+        two = isinstance(optical_props, OpticalProps2str)
+        try:
+            space = _space_of([plev, tlay, optical_props.tau, toa_src])
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+        except KeyError as e:
+            return str(e.args[0])
+        rc = lib().ecckd_gas_optics_sw(
+            self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"), _ptr(tlay, (nlay, ncol), "tlay"),
+            n, names, ptrs, cs, ls, sc, _ptr(optical_props.tau, (ng, nlay, ncol), "tau"),
+            _ptr(optical_props.ssa, (ng, nlay, ncol), "ssa") if two else None,
+            _ptr(optical_props.g, (ng, nlay, ncol), "g") if two else None,
+            _ptr(toa_src, (ng, ncol), "toa_src"), space, _stream(space))
+        return last_error() if rc else ""
+
+
+# ------------------------------------------------------------------------------------------
+# RTE solvers
+# ------------------------------------------------------------------------------------------
+def _device_of(a):
+    if _is_torch(a) and a.is_cuda:
+        return a.device.index if a.device.index is not None else 0
+    return 0
+
+
+def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1, device=None):
+    """``rte_lw(optical_props, top_at_1, sources, sfc_emis(nband,ncol), fluxes, n_gauss_angles=)``
+    (ecckd_rfmip_lw.F90:130-135).  ``sfc_emis`` is ``(ncol, nband)`` in numpy order."""
+    ng, nlay, ncol = optical_props.tau.shape
+    b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
+    nband = b2g.shape[0]
+    space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, fluxes.flux_up, fluxes.flux_dn])
+    dev = _device_of(optical_props.tau) if device is None else device
+    rc = lib().ecckd_rte_lw(
+        int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles),
+        _ptr(optical_props.tau), _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+        _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+        _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+        _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
+        _ptr(sfc_emis, (ncol, nband), "sfc_emis"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+        _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"), space, _stream(space))
+    return last_error() if rc else ""
+
+
+def rte_sw(optical_props, top_at_1, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, fluxes, device=None):
+    """``rte_sw(optical_props, top_at_1, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, fluxes)``
+    (ecckd_rfmip_sw.F90:148-154).  Albedos are ``(ncol, nband)`` in numpy order."""
+    if not isinstance(optical_props, OpticalProps2str):
+        return "rte_sw: two-stream optical properties required"
+    ng, nlay, ncol = optical_props.tau.shape
+    b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
+    nband = b2g.shape[0]
+    space = _space_of([optical_props.tau, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, fluxes.flux_up])
+    dev = _device_of(optical_props.tau) if device is None else device
+    rc = lib().ecckd_rte_sw(
+        int(dev), ncol, nlay, ng, int(bool(top_at_1)), _ptr(optical_props.tau),
+        _ptr(optical_props.ssa, (ng, nlay, ncol), "ssa"), _ptr(optical_props.g, (ng, nlay, ncol), "g"),
+        _ptr(mu0, (ncol,), "mu0"), _ptr(toa_flux, (ng, ncol), "toa_flux"), nband,
+        C.c_void_p(b2g.ctypes.data), _ptr(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"),
+        _ptr(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+        _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
+        _ptr(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))
+    return last_error() if rc else ""

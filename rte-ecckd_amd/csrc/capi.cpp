@@ -1,0 +1,690 @@
+// capi.cpp -- the C ABI of include/ecckd_hip.h: model construction, gas_optics (LW/SW) and the
+// RTE solvers, in device-pointer and host-pointer flavours.  Host logic only; the arithmetic
+// is in kernels_*.hip.  There is deliberately no CPU fallback: a missing/unusable GPU is an
+// error returned to the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ecckd_hip.h"
+#include "kernels.hpp"
+#include "model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+  g_err = msg;
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// trim() of a blank- or NUL-padded character(len=32) record
+std::string trim_name(const char *p) {
+  size_t n = 0;
+  while (n < ECCKD_NAME_LEN && p[n] != '\0') ++n;
+  while (n > 0 && p[n - 1] == ' ') --n;
+  return std::string(p, n);
+}
+
+// Grow-only device arena used by the ECCKD_HOST flavours.
+struct Arena {
+  std::mutex mu;
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) { HIPCHK(hipFree(p)); p = nullptr; bytes = 0; }
+    HIPCHK(hipMalloc(&p, need));
+    bytes = need;
+    return 0;
+  }
+};
+Arena g_solver_arena[16];
+Arena g_scratch_arena[16];   // generic-nlay solver scratch (device flavours too)
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// Bump allocator over an Arena block.
+struct Bump {
+  char *base;
+  size_t off = 0;
+  explicit Bump(void *b) : base(static_cast<char *>(b)) {}
+  double *take(size_t ndoubles) {
+    double *r = reinterpret_cast<double *>(base + off);
+    off += align256(ndoubles * sizeof(double));
+    return r;
+  }
+};
+
+struct GasDesc {   // gas_desc as it crosses the ABI
+  int ngas;
+  const char *names;
+  const double *const *vmr;
+  const long long *cs, *ls;
+  const double *scalar;
+};
+
+size_t vmr_extent(const GasDesc &gd, int j, int ncol, int nlay) {
+  if (!gd.vmr || !gd.vmr[j]) return 0;
+  const long long cs = gd.cs ? gd.cs[j] : 0, ls = gd.ls ? gd.ls[j] : 0;
+  return (size_t)(1 + (long long)(ncol - 1) * cs + (long long)(nlay - 1) * ls);
+}
+
+// gas_optical_depth (src/gas_optics_ecckd.f90:323-376) on device pointers.  `sw` selects the
+// gas_optics_ext epilogue (:455-460).
+int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double *plev,
+                          const double *tlay, const GasDesc &gd, double *tau, bool sw, double *ssa,
+                          double *g, hipStream_t stream) {
+  using namespace ecckd;
+  std::vector<SeqGas> seq;
+  bool first_calc = true;   // :347
+  for (int j = 0; j < gd.ngas; ++j) {   // :348
+    const std::string name = trim_name(gd.names + (size_t)j * ECCKD_NAME_LEN);
+    size_t i = 0;
+    for (; i < m->gas.size(); ++i)
+      if (m->gas[i].name == name) break;   // :349-357
+    if (i >= m->gas.size()) continue;      // :358-364 unknown gas: silently skipped
+    const ecckd_model::Gas &t = m->gas[i];
+    if (t.composite_only && !first_calc) continue;   // :365-367
+    SeqGas e{};
+    e.coef = m->dbuf + t.dev_off;
+    e.vmr = gd.vmr ? gd.vmr[j] : nullptr;
+    e.cs = gd.cs ? gd.cs[j] : 0;
+    e.ls = gd.ls ? gd.ls[j] : 0;
+    e.scalar = gd.scalar ? gd.scalar[j] : 0.;
+    e.ref = t.ref;
+    e.code = t.code;
+    e.nv = t.nv;
+    e.clamp = t.has_negative ? 1 : 0;
+    if (t.code == ECCKD_LOOK_UP_TABLE) {
+      e.mf0 = t.mole_fraction[0];
+      e.log_mf0 = std::log(t.mole_fraction[0]);                          // :156
+      e.d_log_vmr = std::log(t.mole_fraction[1] / t.mole_fraction[0]);   // :154-155
+    }
+    seq.push_back(e);
+    if (t.composite_only) first_calc = false;   // :371-373
+  }
+
+  // Split the sequence into passes holding at most one look_up_table gas each; later passes
+  // start from the tau already stored, so the summation order of :370 is preserved exactly.
+  size_t pos = 0;
+  bool first_pass = true;
+  do {
+    TauArgs a{};
+    a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.np = m->np; a.nt = m->nt;
+    a.plev = plev; a.tlay = tlay;
+    a.temperature = m->dbuf + m->off_temperature;
+    a.lp0 = m->log_pressure[0];                               // :104
+    a.dlp = m->log_pressure[1] - m->log_pressure[0];          // :105
+    a.dt = m->temperature[m->np] - m->temperature[0];         // :106 T(1,2)-T(1,1)
+    // :107  1./(gravity*0.001*dry_air_molar_mass) with default-real literals (:51-52)
+    a.gw = 1. / ((double)9.80665f * (double)0.001f * (double)28.970f);
+    a.lut = -1;
+    a.nbil = 0;
+    a.nseq = 0;
+    while (pos < seq.size()) {
+      SeqGas e = seq[pos];
+      if (e.code == ECCKD_LOOK_UP_TABLE) {
+        if (a.lut >= 0) break;
+        a.lut = a.nseq;
+      } else {
+        e.slot = a.nbil;
+        a.bil_seq[a.nbil++] = a.nseq;
+      }
+      a.seq[a.nseq++] = e;
+      ++pos;
+    }
+    a.accumulate = first_pass ? 0 : 1;
+    a.tau = tau;
+    const bool last = pos >= seq.size();
+    if (sw && last) {
+      a.rayleigh = m->dbuf + m->off_rayleigh;
+      a.ssa = ssa;
+      a.g = g;
+    }
+    HIPCHK(launch_tau(a, stream));
+    first_pass = false;
+  } while (pos < seq.size());
+  return 0;
+}
+
+int check_model(const ecckd_model *m) {
+  if (!m) return fail("ecckd: null model");
+  if (!m->finalized) return fail("ecckd: model is not finalized");
+  return 0;
+}
+
+int check_dims(int ncol, int nlay) {
+  if (ncol < 0 || nlay < 1) return fail("ecckd: bad ncol/nlay");
+  return 0;
+}
+
+// Copies gas_desc data arrays to the arena and returns the device-side description.
+struct StagedGases {
+  std::vector<const double *> ptr;
+  GasDesc gd;
+};
+size_t staged_gas_bytes(const GasDesc &gd, int ncol, int nlay) {
+  size_t b = 0;
+  for (int j = 0; j < gd.ngas; ++j) b += align256(vmr_extent(gd, j, ncol, nlay) * sizeof(double));
+  return b;
+}
+int stage_gases(const GasDesc &gd, int ncol, int nlay, Bump &bump, hipStream_t s, StagedGases &out) {
+  out.ptr.assign(gd.ngas, nullptr);
+  for (int j = 0; j < gd.ngas; ++j) {
+    const size_t n = vmr_extent(gd, j, ncol, nlay);
+    if (!n) continue;
+    double *d = bump.take(n);
+    HIPCHK(hipMemcpyAsync(d, gd.vmr[j], n * sizeof(double), hipMemcpyHostToDevice, s));
+    out.ptr[j] = d;
+  }
+  out.gd = gd;
+  out.gd.vmr = out.ptr.data();
+  return 0;
+}
+
+int h2d(double *d, const double *h, size_t n, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, s));
+  return 0;
+}
+int d2h(double *h, const double *d, size_t n, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int fill_band_map(int ngpt, int nband, const int *band2gpt, unsigned char *gpt2band) {
+  if (ngpt < 1 || ngpt > 256) return fail("ecckd: ngpt must be in 1..256");
+  if (nband < 1 || nband > 255 || !band2gpt) return fail("ecckd: bad band description");
+  std::memset(gpt2band, 0, 256);
+  std::vector<int> seen(ngpt, 0);
+  for (int b = 0; b < nband; ++b) {
+    const int lo = band2gpt[2 * b], hi = band2gpt[2 * b + 1];
+    if (lo < 1 || hi > ngpt || lo > hi) return fail("ecckd: band2gpt out of range");
+    for (int gpt = lo; gpt <= hi; ++gpt) { gpt2band[gpt - 1] = (unsigned char)b; seen[gpt - 1] = 1; }
+  }
+  for (int i = 0; i < ngpt; ++i)
+    if (!seen[i]) return fail("ecckd: band2gpt does not cover every g-point");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ecckd_last_error(void) { return g_err.c_str(); }
+
+const char *ecckd_build_info(void) {
+  return "rte-ecckd hot path for MI355X: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, fp64";
+}
+
+// ------------------------------- model construction -------------------------------------
+
+int ecckd_model_begin(int ng, int np, int nt, const double *log_pressure, const double *temperature,
+                      ecckd_model_t **model) {
+  if (!model) return fail("ecckd_model_begin: null output");
+  *model = nullptr;
+  if (ng < 1 || np < 2 || nt < 2 || !log_pressure || !temperature)
+    return fail("ecckd_model_begin: bad dimensions or null tables");
+  ecckd_model *m = new ecckd_model;
+  m->ng = ng; m->np = np; m->nt = nt;
+  m->log_pressure.assign(log_pressure, log_pressure + np);
+  m->temperature.assign(temperature, temperature + (size_t)np * nt);
+  // default band structure: a single band over all g-points
+  m->nband = 1;
+  m->band2gpt = {1, ng};
+  m->band_lims_wvn = {0., 0.};
+  *model = m;
+  return 0;
+}
+
+int ecckd_model_set_planck(ecckd_model_t *m, int ntp, const double *temperature_planck,
+                           const double *planck_function) {
+  if (!m || m->finalized) return fail("ecckd_model_set_planck: model missing or frozen");
+  if (ntp < 2 || !temperature_planck || !planck_function) return fail("ecckd_model_set_planck: bad table");
+  m->ntp = ntp;
+  m->temperature_planck.assign(temperature_planck, temperature_planck + ntp);
+  m->planck_function.assign(planck_function, planck_function + (size_t)m->ng * ntp);
+  m->has_planck = true;
+  return 0;
+}
+
+int ecckd_model_set_solar(ecckd_model_t *m, const double *solar_irradiance, const double *rayleigh) {
+  if (!m || m->finalized) return fail("ecckd_model_set_solar: model missing or frozen");
+  if (!solar_irradiance || !rayleigh) return fail("ecckd_model_set_solar: null table");
+  m->solar_irradiance.assign(solar_irradiance, solar_irradiance + m->ng);
+  m->rayleigh.assign(rayleigh, rayleigh + m->ng);
+  m->total_solar_irradiance = 0.;
+  for (double s : m->solar_irradiance) m->total_solar_irradiance += s;   // mo_load_coefficients.F90:89
+  m->has_solar = true;
+  return 0;
+}
+
+int ecckd_model_set_bands(ecckd_model_t *m, int nband, const double *band_lims_wvn, const int *band2gpt) {
+  if (!m || m->finalized) return fail("ecckd_model_set_bands: model missing or frozen");
+  unsigned char tmp[256];
+  if (fill_band_map(m->ng, nband, band2gpt, tmp)) return 1;
+  m->nband = nband;
+  m->band2gpt.assign(band2gpt, band2gpt + 2 * (size_t)nband);
+  if (band_lims_wvn) m->band_lims_wvn.assign(band_lims_wvn, band_lims_wvn + 2 * (size_t)nband);
+  else m->band_lims_wvn.assign(2 * (size_t)nband, 0.);
+  return 0;
+}
+
+int ecckd_model_add_gas(ecckd_model_t *m, const char *name, int code, int composite_only, int nv,
+                        const double *mole_fraction, double reference_mole_fraction,
+                        const double *coefficient) {
+  if (!m || m->finalized) return fail("ecckd_model_add_gas: model missing or frozen");
+  if (!name || !coefficient) return fail("ecckd_model_add_gas: null argument");
+  if (m->gas.size() >= ECCKD_MAX_GASES) return fail("ecckd_model_add_gas: more than 16 gases");
+  if (code < 0 || code > 3) return fail(std::string("load_and_init_ecckd: bad concentration code for ") + name);
+  ecckd_model::Gas g;
+  g.name = trim_name(name);
+  g.code = code;
+  g.composite_only = composite_only ? 1 : 0;
+  g.ref = reference_mole_fraction;
+  if (code == ECCKD_LOOK_UP_TABLE) {
+    if (nv < 2 || !mole_fraction) return fail("ecckd_model_add_gas: look_up_table gas needs mole_fraction(nv>=2)");
+    g.nv = nv;
+    g.mole_fraction.assign(mole_fraction, mole_fraction + nv);
+  } else {
+    g.nv = 1;
+  }
+  g.coef.assign(coefficient, coefficient + (size_t)m->ng * m->np * m->nt * g.nv);
+  m->gas.push_back(std::move(g));
+  return 0;
+}
+
+int ecckd_model_finalize(ecckd_model_t *m, int device) {
+  if (!m) return fail("ecckd_model_finalize: null model");
+  if (m->finalized) return fail("ecckd_model_finalize: already finalized");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail("ecckd: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev || device >= 16) return fail("ecckd_model_finalize: bad device ordinal");
+  HIPCHK(hipSetDevice(device));
+  // layout of the single device buffer
+  std::vector<double> host;
+  auto put = [&](const std::vector<double> &v) {
+    size_t off = host.size();
+    host.insert(host.end(), v.begin(), v.end());
+    while (host.size() % 32) host.push_back(0.);
+    return off;
+  };
+  m->off_temperature = put(m->temperature);
+  if (m->has_planck) m->off_planck = put(m->planck_function);
+  if (m->has_solar) { m->off_rayleigh = put(m->rayleigh); m->off_solar = put(m->solar_irradiance); }
+  for (size_t i = 0; i < m->gas.size(); ++i) {
+    ecckd_model::Gas &g = m->gas[i];
+    g.has_negative = false;
+    for (double c : g.coef)
+      if (!(c >= 0.)) { g.has_negative = true; break; }   // negatives or NaN: keep the per-g clamp
+    bool shared = false;
+    for (size_t k = 0; k < i && !shared; ++k) {   // o2/n2 carry identical composite tables
+      const ecckd_model::Gas &o = m->gas[k];
+      if (o.coef.size() == g.coef.size() &&
+          std::memcmp(o.coef.data(), g.coef.data(), g.coef.size() * sizeof(double)) == 0) {
+        g.dev_off = o.dev_off;
+        shared = true;
+      }
+    }
+    if (!shared) g.dev_off = put(g.coef);
+  }
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->dbuf), host.size() * sizeof(double)));
+  HIPCHK(hipMemcpy(m->dbuf, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
+  m->device = device;
+  m->finalized = true;
+  return 0;
+}
+
+int ecckd_model_load(const char *filename, int device, ecckd_model_t **model) {
+  if (!model || !filename) return fail("ecckd_model_load: null argument");
+  *model = nullptr;
+  ecckd_model *m = new ecckd_model;
+  try {
+    ecckd::load_and_init(*m, filename);
+  } catch (const std::exception &e) {
+    delete m;
+    return fail(e.what());
+  }
+  if (ecckd_model_finalize(m, device)) {
+    delete m;
+    return 1;
+  }
+  *model = m;
+  return 0;
+}
+
+void ecckd_model_destroy(ecckd_model_t *m) {
+  if (!m) return;
+  if (m->finalized) {
+    (void)hipSetDevice(m->device);
+    if (m->host_stream) (void)hipStreamDestroy(m->host_stream);
+    if (m->arena) (void)hipFree(m->arena);
+    if (m->dbuf) (void)hipFree(m->dbuf);
+  }
+  delete m;
+}
+
+// ------------------------------------- getters -------------------------------------------
+
+int ecckd_model_get_ngpt(const ecckd_model_t *m) { return m ? m->ng : 0; }
+int ecckd_model_get_nband(const ecckd_model_t *m) { return m ? m->nband : 0; }
+int ecckd_model_get_ngas(const ecckd_model_t *m) { return m ? (int)m->gas.size() : 0; }
+int ecckd_model_get_gas_name(const ecckd_model_t *m, int index, char *name) {
+  if (!m || !name || index < 0 || index >= (int)m->gas.size()) return fail("ecckd_model_get_gas_name: bad index");
+  std::memset(name, 0, ECCKD_NAME_LEN);
+  std::strncpy(name, m->gas[index].name.c_str(), ECCKD_NAME_LEN - 1);
+  return 0;
+}
+int ecckd_model_source_is_internal(const ecckd_model_t *m) { return m && m->has_planck; }
+int ecckd_model_source_is_external(const ecckd_model_t *m) { return m && m->has_solar; }
+double ecckd_model_get_press_min(const ecckd_model_t *m) { return m ? std::exp(m->log_pressure.front()) : 0.; }
+double ecckd_model_get_press_max(const ecckd_model_t *m) { return m ? std::exp(m->log_pressure.back()) : 0.; }
+double ecckd_model_get_temp_min(const ecckd_model_t *m) {
+  if (!m) return 0.;
+  double v = m->temperature[0];
+  for (double t : m->temperature) v = t < v ? t : v;
+  return v;
+}
+double ecckd_model_get_temp_max(const ecckd_model_t *m) {
+  if (!m) return 0.;
+  double v = m->temperature[0];
+  for (double t : m->temperature) v = t > v ? t : v;
+  return v;
+}
+double ecckd_model_get_total_solar_irradiance(const ecckd_model_t *m) { return m ? m->total_solar_irradiance : 0.; }
+int ecckd_model_get_band2gpt(const ecckd_model_t *m, int *band2gpt) {
+  if (!m || !band2gpt) return fail("ecckd_model_get_band2gpt: null argument");
+  std::memcpy(band2gpt, m->band2gpt.data(), m->band2gpt.size() * sizeof(int));
+  return 0;
+}
+int ecckd_model_get_band_lims_wvn(const ecckd_model_t *m, double *lims) {
+  if (!m || !lims) return fail("ecckd_model_get_band_lims_wvn: null argument");
+  std::memcpy(lims, m->band_lims_wvn.data(), m->band_lims_wvn.size() * sizeof(double));
+  return 0;
+}
+int ecckd_model_get_device(const ecckd_model_t *m) { return m ? m->device : -1; }
+
+// ------------------------------------ gas optics -----------------------------------------
+
+static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const double *plev,
+                             const double *tlay, const double *tsfc, const double *tlev,
+                             const GasDesc &gd, double *tau, double *lay_source, double *lev_inc,
+                             double *lev_dec, double *sfc_source, hipStream_t stream) {
+  if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, false, nullptr, nullptr, stream)) return 1;   // :401
+  ecckd::PlanckArgs p{};
+  p.ncol = ncol; p.nlay = nlay; p.ng = m->ng; p.ntp = m->ntp;
+  p.planck = m->dbuf + m->off_planck;
+  p.t0 = m->temperature_planck[0];                                  // :272
+  p.dt = m->temperature_planck[1] - m->temperature_planck[0];      // :271
+  p.tlay = tlay; p.tlev = tlev; p.tsfc = tsfc;
+  p.lay_source = lay_source; p.lev_source_inc = lev_inc; p.lev_source_dec = lev_dec;
+  p.sfc_source = sfc_source;
+  HIPCHK(ecckd::launch_planck(p, stream));                          // :407-424
+  return 0;
+}
+
+int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double *plev,
+                        const double *tlay, const double *tsfc, const double *tlev, int ngas,
+                        const char *gas_names, const double *const *vmr,
+                        const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                        const double *vmr_scalar, double *tau, double *lay_source,
+                        double *lev_source_inc, double *lev_source_dec, double *sfc_source,
+                        int memspace, void *stream) {
+  if (check_model(m) || check_dims(ncol, nlay)) return 1;
+  if (!m->has_planck) return fail("ecckd_gas_optics_lw: model has no Planck table (shortwave model?)");
+  if (!plev || !tlay || !tsfc || !tau || !lay_source || !sfc_source || (ngas > 0 && !gas_names))
+    return fail("ecckd_gas_optics_lw: null argument");
+  if (tlev && (!lev_source_inc || !lev_source_dec)) return fail("ecckd_gas_optics_lw: null level sources");
+  HIPCHK(hipSetDevice(m->device));
+  const GasDesc gd{ngas, gas_names, vmr, vmr_col_stride, vmr_lay_stride, vmr_scalar};
+  const size_t n2 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1), n3 = n2 * m->ng;
+  if (ncol == 0) return tlev ? 0 : fail("tlev is required for ecckd");
+
+  if (memspace == ECCKD_DEVICE) {
+    if (gas_optics_lw_dev(m, ncol, nlay, plev, tlay, tsfc, tlev, gd, tau, lay_source, lev_source_inc,
+                          lev_source_dec, sfc_source, static_cast<hipStream_t>(stream)))
+      return 1;
+    return tlev ? 0 : fail("tlev is required for ecckd");   // :414-417
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+
+  ecckd_model *mm = const_cast<ecckd_model *>(m);
+  std::lock_guard<std::mutex> lock(mm->mu);
+  hipStream_t s = mm->host_stream;
+  size_t need = align256(n2l * 8) * 2 + align256(n2 * 8) + align256((size_t)ncol * 8) +
+                staged_gas_bytes(gd, ncol, nlay) + align256(n3 * 8) * 4 + align256((size_t)ncol * m->ng * 8);
+  if (need > mm->arena_bytes) {
+    if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
+    HIPCHK(hipMalloc(&mm->arena, need));
+    mm->arena_bytes = need;
+  }
+  Bump b(mm->arena);
+  double *d_plev = b.take(n2l), *d_tlev = b.take(n2l), *d_tlay = b.take(n2), *d_tsfc = b.take(ncol);
+  if (h2d(d_plev, plev, n2l, s) || h2d(d_tlay, tlay, n2, s) || h2d(d_tsfc, tsfc, ncol, s)) return 1;
+  if (tlev && h2d(d_tlev, tlev, n2l, s)) return 1;
+  StagedGases sg;
+  if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
+  double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
+  double *d_sfc = b.take((size_t)ncol * m->ng);
+  if (gas_optics_lw_dev(m, ncol, nlay, d_plev, d_tlay, d_tsfc, tlev ? d_tlev : nullptr, sg.gd, d_tau,
+                        d_lay, d_inc, d_dec, d_sfc, s))
+    return 1;
+  if (d2h(tau, d_tau, n3, s) || d2h(lay_source, d_lay, n3, s) ||
+      d2h(sfc_source, d_sfc, (size_t)ncol * m->ng, s))
+    return 1;
+  if (tlev && (d2h(lev_source_inc, d_inc, n3, s) || d2h(lev_source_dec, d_dec, n3, s))) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return tlev ? 0 : fail("tlev is required for ecckd");
+}
+
+static int gas_optics_sw_dev(const ecckd_model *m, int ncol, int nlay, const double *plev,
+                             const double *tlay, const GasDesc &gd, double *tau, double *ssa,
+                             double *g, double *toa_src, hipStream_t stream) {
+  const bool two_stream = ssa && g;
+  if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, true, two_stream ? ssa : nullptr,
+                            two_stream ? g : nullptr, stream))   // :449-460
+    return 1;
+  if (!two_stream) return 0;   // caller reports :461-463 after tau has been written
+  HIPCHK(ecckd::launch_toa_src(m->dbuf + m->off_solar, ncol, m->ng, toa_src, stream));   // :468-472
+  return 0;
+}
+
+int ecckd_gas_optics_sw(const ecckd_model_t *m, int ncol, int nlay, const double *plev,
+                        const double *tlay, int ngas, const char *gas_names,
+                        const double *const *vmr, const long long *vmr_col_stride,
+                        const long long *vmr_lay_stride, const double *vmr_scalar, double *tau,
+                        double *ssa, double *g, double *toa_src, int memspace, void *stream) {
+  if (check_model(m) || check_dims(ncol, nlay)) return 1;
+  if (!m->has_solar) return fail("ecckd_gas_optics_sw: model has no solar table (longwave model?)");
+  if (!plev || !tlay || !tau || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_sw: null argument");
+  const bool two_stream = ssa && g;
+  if (two_stream && !toa_src) return fail("ecckd_gas_optics_sw: null toa_src");
+  HIPCHK(hipSetDevice(m->device));
+  const GasDesc gd{ngas, gas_names, vmr, vmr_col_stride, vmr_lay_stride, vmr_scalar};
+  const size_t n2 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1), n3 = n2 * m->ng;
+  static const char *kNot2str = "shortwave must use ty_optical_props_2str";   // :462
+  if (ncol == 0) return two_stream ? 0 : fail(kNot2str);
+
+  if (memspace == ECCKD_DEVICE) {
+    if (gas_optics_sw_dev(m, ncol, nlay, plev, tlay, gd, tau, ssa, g, toa_src, static_cast<hipStream_t>(stream)))
+      return 1;
+    return two_stream ? 0 : fail(kNot2str);
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+
+  ecckd_model *mm = const_cast<ecckd_model *>(m);
+  std::lock_guard<std::mutex> lock(mm->mu);
+  hipStream_t s = mm->host_stream;
+  size_t need = align256(n2l * 8) + align256(n2 * 8) + staged_gas_bytes(gd, ncol, nlay) +
+                align256(n3 * 8) * 3 + align256((size_t)ncol * m->ng * 8);
+  if (need > mm->arena_bytes) {
+    if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
+    HIPCHK(hipMalloc(&mm->arena, need));
+    mm->arena_bytes = need;
+  }
+  Bump b(mm->arena);
+  double *d_plev = b.take(n2l), *d_tlay = b.take(n2);
+  if (h2d(d_plev, plev, n2l, s) || h2d(d_tlay, tlay, n2, s)) return 1;
+  StagedGases sg;
+  if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
+  double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3);
+  double *d_toa = b.take((size_t)ncol * m->ng);
+  if (gas_optics_sw_dev(m, ncol, nlay, d_plev, d_tlay, sg.gd, d_tau, two_stream ? d_ssa : nullptr,
+                        two_stream ? d_g : nullptr, d_toa, s))
+    return 1;
+  if (d2h(tau, d_tau, n3, s)) return 1;
+  if (two_stream && (d2h(ssa, d_ssa, n3, s) || d2h(g, d_g, n3, s) || d2h(toa_src, d_toa, (size_t)ncol * m->ng, s)))
+    return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return two_stream ? 0 : fail(kNot2str);
+}
+
+// -------------------------------------- solvers ------------------------------------------
+
+// Gauss-Jacobi-5 quadrature of RTE-RRTMGP's mo_rte_lw (secants and weights for 1..4 angles;
+// ecckd_rfmip_lw.F90:40-44 selects 1 or 3).
+static const double kGaussDs[4][4] = {{1.66, 0., 0., 0.},
+                                      {1.18350343, 2.81649655, 0., 0.},
+                                      {1.09719858, 1.69338507, 4.70941630, 0.},
+                                      {1.06056257, 1.38282560, 2.40148179, 7.15513024}};
+static const double kGaussWts[4][4] = {{0.5, 0., 0., 0.},
+                                       {0.3180413817, 0.1819586183, 0., 0.},
+                                       {0.2009319137, 0.2292411064, 0.0698269799, 0.},
+                                       {0.1355069134, 0.2034645680, 0.1298475476, 0.0311809710}};
+
+static int check_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail("ecckd: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev || device >= 16) return fail("ecckd: bad device ordinal");
+  HIPCHK(hipSetDevice(device));
+  return 0;
+}
+
+int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                 const double *tau, const double *lay_source, const double *lev_source_inc,
+                 const double *lev_source_dec, const double *sfc_source, int nband,
+                 const int *band2gpt, const double *sfc_emis, double *flux_up, double *flux_dn,
+                 int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  if (n_gauss_angles < 1 || n_gauss_angles > 4) return fail("rte_lw: have to ask for at least one quadrature point and no more than 4");
+  if (!tau || !lay_source || !lev_source_inc || !lev_source_dec || !sfc_source || !sfc_emis || !flux_up || !flux_dn)
+    return fail("ecckd_rte_lw: null argument");
+  ecckd::RteLwArgs a{};
+  if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
+  if (check_device(device)) return 1;
+  if (ncol == 0) return 0;
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
+  a.nband = nband;
+  for (int k = 0; k < n_gauss_angles; ++k) {
+    a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
+    a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
+  }
+  const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
+  const size_t scratch = ecckd::rte_lw_scratch_bytes(ncol, nlay, ngpt);
+  Arena &sa = g_scratch_arena[device];
+  std::unique_lock<std::mutex> slock(sa.mu, std::defer_lock);
+  if (scratch) {
+    slock.lock();
+    if (sa.ensure(scratch)) return 1;
+    a.scratch = static_cast<double *>(sa.p);
+  }
+  if (memspace == ECCKD_DEVICE) {
+    a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc;
+    a.lev_source_dec = lev_source_dec; a.sfc_source = sfc_source; a.sfc_emis = sfc_emis;
+    a.flux_up = flux_up; a.flux_dn = flux_dn;
+    HIPCHK(ecckd::launch_rte_lw(a, static_cast<hipStream_t>(stream)));
+    if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // scratch is shared
+    return 0;
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  Arena &ar = g_solver_arena[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  const size_t need = align256(n3 * 8) * 4 + align256((size_t)ncol * ngpt * 8) +
+                      align256((size_t)ncol * nband * 8) + align256(n2l * 8) * 2;
+  if (ar.ensure(need)) return 1;
+  Bump b(ar.p);
+  double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
+  double *d_sfc = b.take((size_t)ncol * ngpt), *d_emis = b.take((size_t)ncol * nband);
+  double *d_up = b.take(n2l), *d_dn = b.take(n2l);
+  hipStream_t s = nullptr;
+  if (h2d(d_tau, tau, n3, s) || h2d(d_lay, lay_source, n3, s) || h2d(d_inc, lev_source_inc, n3, s) ||
+      h2d(d_dec, lev_source_dec, n3, s) || h2d(d_sfc, sfc_source, (size_t)ncol * ngpt, s) ||
+      h2d(d_emis, sfc_emis, (size_t)ncol * nband, s))
+    return 1;
+  a.tau = d_tau; a.lay_source = d_lay; a.lev_source_inc = d_inc; a.lev_source_dec = d_dec;
+  a.sfc_source = d_sfc; a.sfc_emis = d_emis; a.flux_up = d_up; a.flux_dn = d_dn;
+  HIPCHK(ecckd::launch_rte_lw(a, s));
+  if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
+                 const double *ssa, const double *g, const double *mu0, const double *toa_flux,
+                 int nband, const int *band2gpt, const double *sfc_alb_dir,
+                 const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
+                 int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  if (!tau || !ssa || !g || !mu0 || !toa_flux || !sfc_alb_dir || !sfc_alb_dif || !flux_up || !flux_dn)
+    return fail("ecckd_rte_sw: null argument");
+  ecckd::RteSwArgs a{};
+  if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
+  if (check_device(device)) return 1;
+  if (ncol == 0) return 0;
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nband = nband;
+  const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
+  const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
+  Arena &sa = g_scratch_arena[device];
+  std::unique_lock<std::mutex> slock(sa.mu, std::defer_lock);
+  if (scratch) {
+    slock.lock();
+    if (sa.ensure(scratch)) return 1;
+    a.scratch = static_cast<double *>(sa.p);
+  }
+  if (memspace == ECCKD_DEVICE) {
+    a.tau = tau; a.ssa = ssa; a.g = g; a.mu0 = mu0; a.toa = toa_flux;
+    a.alb_dir = sfc_alb_dir; a.alb_dif = sfc_alb_dif;
+    a.flux_up = flux_up; a.flux_dn = flux_dn; a.flux_dir = flux_dir;
+    HIPCHK(ecckd::launch_rte_sw(a, static_cast<hipStream_t>(stream)));
+    if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return 0;
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  Arena &ar = g_solver_arena[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  const size_t need = align256(n3 * 8) * 3 + align256((size_t)ncol * 8) + align256((size_t)ncol * ngpt * 8) +
+                      align256((size_t)ncol * nband * 8) * 2 + align256(n2l * 8) * 3;
+  if (ar.ensure(need)) return 1;
+  Bump b(ar.p);
+  double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3), *d_mu0 = b.take(ncol);
+  double *d_toa = b.take((size_t)ncol * ngpt), *d_ad = b.take((size_t)ncol * nband), *d_af = b.take((size_t)ncol * nband);
+  double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_dir = b.take(n2l);
+  hipStream_t s = nullptr;
+  if (h2d(d_tau, tau, n3, s) || h2d(d_ssa, ssa, n3, s) || h2d(d_g, g, n3, s) || h2d(d_mu0, mu0, ncol, s) ||
+      h2d(d_toa, toa_flux, (size_t)ncol * ngpt, s) || h2d(d_ad, sfc_alb_dir, (size_t)ncol * nband, s) ||
+      h2d(d_af, sfc_alb_dif, (size_t)ncol * nband, s))
+    return 1;
+  a.tau = d_tau; a.ssa = d_ssa; a.g = d_g; a.mu0 = d_mu0; a.toa = d_toa; a.alb_dir = d_ad; a.alb_dif = d_af;
+  a.flux_up = d_up; a.flux_dn = d_dn; a.flux_dir = flux_dir ? d_dir : nullptr;
+  HIPCHK(ecckd::launch_rte_sw(a, s));
+  if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
+  if (flux_dir && d2h(flux_dir, d_dir, n2l, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// kernels.hpp -- launch interface between the C ABI (capi.cpp) and the gfx950 kernels.
+// All pointers are device pointers on the current device; every array is column-major with the
+// column index fastest (the reference's layout, src/gas_optics_ecckd.f90:69-72).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ecckd {
+
+constexpr int kMaxSeq = 16;          // src/gas_optics_ecckd.f90:24 (at most 16 tables)
+constexpr int kLdsBudget = 160 * 1024;
+
+// One entry of the per-call gas sequence: a table of the model matched to a gas of gas_desc,
+// in gas_desc order (src/gas_optics_ecckd.f90:348-374).
+struct SeqGas {
+  const double *coef;     // (ng,np,nt,nv) table in device memory
+  const double *vmr;      // device pointer or nullptr -> scalar
+  long long cs, ls;       // vmr(i,l) = vmr[i*cs + l*ls]
+  double scalar;
+  double ref;             // reference_mole_fraction (relative_linear)
+  double mf0;             // mole_fraction(1)                       (look_up_table)
+  double log_mf0;         // log(mole_fraction(1))                  (host libm, as the reference)
+  double d_log_vmr;       // log(mole_fraction(2)/mole_fraction(1)) (host libm)
+  int code;               // ECCKD_NONE / LINEAR / LOOK_UP_TABLE / RELATIVE_LINEAR
+  int nv;
+  int slot;               // bilinear: slot inside a slab row; LUT: unused
+  int clamp;              // 1 if the table holds negative coefficients -> per-g clamp needed
+};
+
+struct TauArgs {
+  int ncol, nlay, ng, np, nt;
+  const double *plev, *tlay;
+  const double *temperature;   // (np,nt) device; only T(:,1) is used (:131-132)
+  double lp0, dlp, dt, gw;     // :104-107
+  int nseq;
+  SeqGas seq[kMaxSeq];
+  int nbil;                    // bilinear gases in this pass (slab row holds nbil*ng values)
+  int bil_seq[kMaxSeq];        // slab slot -> index into seq
+  int lut;                     // index into seq of the look_up_table gas, or -1
+  int accumulate;              // start from the tau already in memory (later passes)
+  double *tau;
+  // shortwave epilogue (src/gas_optics_ecckd.f90:455-460); rayleigh == nullptr for LW
+  const double *rayleigh;
+  double *ssa, *g;
+  // launch geometry chosen by the host
+  int R;                       // pressure rows of the LDS slab
+  int col_chunks;              // grid.x; each block walks tiles chunk by chunk
+};
+
+struct PlanckArgs {
+  int ncol, nlay, ng, ntp;
+  const double *planck;        // (ng,ntp) device
+  double t0, dt;               // temperature_planck(1), (2)-(1)   (:271-272)
+  const double *tlay, *tlev, *tsfc;    // tlev may be nullptr
+  double *lay_source, *lev_source_inc, *lev_source_dec, *sfc_source;
+  int lev_chunks;              // grid.y
+};
+
+struct RteLwArgs {
+  int ncol, nlay, ng, top_at_1, nmus;
+  double Ds[4], wts[4];
+  const double *tau, *lay_source, *lev_source_inc, *lev_source_dec, *sfc_source;
+  const double *sfc_emis;      // (nband,ncol)
+  int nband;
+  unsigned char gpt2band[256]; // 0-based band of each g-point
+  double *flux_up, *flux_dn;
+  double *scratch;             // generic-nlay path only
+};
+
+struct RteSwArgs {
+  int ncol, nlay, ng, top_at_1;
+  const double *tau, *ssa, *g, *mu0, *toa;
+  const double *alb_dir, *alb_dif;   // (nband,ncol)
+  int nband;
+  unsigned char gpt2band[256];
+  double *flux_up, *flux_dn, *flux_dir;   // flux_dir may be nullptr
+  double *scratch;
+};
+
+// Host-side helpers -------------------------------------------------------------------------
+int tau_slab_rows(int ng, int np, int nt, int nbil, int nv_lut);   // R that fits LDS (>= 0)
+size_t tau_lds_bytes(int ng, int np, int nt, int nbil, int nv_lut, int R);
+size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
+size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
+
+hipError_t launch_tau(TauArgs &a, hipStream_t s);
+hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
+hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);
+hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);
+hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s);
+
+}  // namespace ecckd

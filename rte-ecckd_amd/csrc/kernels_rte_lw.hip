@@ -1,0 +1,241 @@
+// kernels_rte_lw.hip -- longwave no-scattering flux solver with the broadband g-point
+// reduction fused in.
+//
+// Replaces RTE-RRTMGP's rte_lw as the reference calls it (example/rfmip-rad-irf/
+// ecckd_rfmip_lw.F90:130-135): lw_solver_noscat_GaussQuad (transmittance, lw_source_noscat,
+// lw_transport_noscat) followed by ty_fluxes_broadband%reduce (sum_broadband).
+//
+// Mapping (gfx950): one wave = CW columns x GW=64/CW g-points.  A load instruction therefore
+// touches GW segments of CW*8 B (whole 128 B lines for CW=16) of the column-fastest inputs.
+// Each lane owns one (column, g-point) pair at a time and walks the layer recurrence:
+//   down sweep: reads tau/lay_source/lev_source_{inc,dec} ONCE (4x8 B per cell, software
+//               prefetched PF layers ahead), keeps trans(l) and source_up(l) in registers
+//               (fully unrolled over NL layers), accumulates 2*pi*w*I_dn per level;
+//   up sweep:   runs out of registers, accumulates 2*pi*w*I_up per level.
+// The sum over g-points is a wave shuffle butterfly over the GW lanes that share a column
+// followed by an add into a wave-private LDS accumulator (no inter-wave traffic, no atomics,
+// deterministic).  After the last g-point group the accumulators are the broadband fluxes.
+// Registers (512 per lane at one wave per SIMD) are the only place on the chip large enough
+// for the 2*NL doubles per pair that the up sweep needs; the HBM latency is hidden by the
+// explicit prefetch ring instead of by occupancy.
+//
+// NL > 0 requires nlay == NL exactly (no per-layer predicates in the unrolled code).
+// NL == 0 is the any-nlay fallback: trans/source_up go through a global scratch ring instead
+// of registers (twice the memory traffic, but high occupancy).
+#include "kernels.hpp"
+
+namespace ecckd {
+namespace {
+
+constexpr int kPF = 4;   // prefetch depth in layers
+constexpr int kSchedSpan = 2;   // layers the instruction scheduler may interleave
+
+template <int CW>
+__device__ __forceinline__ double gsum(double v) {
+  // sum over the lanes that share a column: lane = cl + CW*gs
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
+  return v;
+}
+
+// acc += v by the owner lane (gs == 0) only.  The other lanes add +0.0 to the same word, which
+// leaves the sum bit-identical whatever order the LDS unit serialises them in; one fire-and-
+// forget ds_add_f64 replaces an exec-masked read/wait/add/write that would expose the full LDS
+// latency twice per layer at one wave per SIMD.
+__device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
+  __hip_atomic_fetch_add(p, owner ? v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <int NL, int CW>
+__global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
+  constexpr int GW = 64 / CW;
+  extern __shared__ double acc[];   // [2][nlay+1][CW]
+  const int lane = threadIdx.x;
+  const int cl = lane % CW, gs = lane / CW;
+  const bool owner = gs == 0;
+  const int ncol = a.ncol, nlay = a.nlay, ng = a.ng;
+  const int nlev = nlay + 1;
+  double *acc_dn = acc, *acc_up = acc + nlev * CW;
+  const double pi = acos(-1.);
+  const double tau_thresh = 1.4901161193847656e-08;   // sqrt(epsilon(1._wp))
+  // layer / level walked s-th from the top lives at index l0 + s*lstep
+  const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
+  const long lstep = a.top_at_1 ? 1 : -1;
+  const double *Bdn = a.top_at_1 ? a.lev_source_inc : a.lev_source_dec;
+  const double *Bup = a.top_at_1 ? a.lev_source_dec : a.lev_source_inc;
+  const int ngroups = (ng + GW - 1) / GW;
+  const int niter = ngroups * a.nmus;
+  const long ntiles = ((long)ncol + CW - 1) / CW;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long col = tile * CW + cl;
+    const bool valid = col < ncol;
+    const long cc = valid ? col : (long)ncol - 1;
+    for (int i = lane; i < 2 * nlev * CW; i += 64) acc[i] = 0.;
+
+    [[maybe_unused]] double T[NL > 0 ? NL : 1], SU[NL > 0 ? NL : 1];
+    [[maybe_unused]] double *sT = nullptr, *sSU = nullptr;
+    if constexpr (NL == 0) {
+      sT = a.scratch + ((long)blockIdx.x * 2 * nlay) * 64 + lane;
+      sSU = sT + (long)nlay * 64;
+    }
+    double ptau[kPF], play[kPF], pbdn[kPF], pbup[kPF];
+
+    // Element offset of the next layer to prefetch.  It is advanced step by step and made
+    // opaque to the optimiser after every advance: otherwise the fully unrolled layer loop is
+    // rewritten as base + s*step with 60 loop-invariant scalar offsets that spill the SGPR file.
+    long qn = 0;
+    const long qstep = (long)ncol * lstep;
+    auto pair_start = [&](int it) {
+      const int g = (it / a.nmus) * GW + gs;
+      const int gg = g < ng ? g : ng - 1;
+      qn = cc + (long)ncol * nlay * gg + (long)ncol * lay0;
+      asm volatile("" : "+v"(qn));
+    };
+    auto issue = [&](int slot) {
+      ptau[slot] = a.tau[qn];
+      play[slot] = a.lay_source[qn];
+      pbdn[slot] = Bdn[qn];
+      pbup[slot] = Bup[qn];
+      qn += qstep;
+      asm volatile("" : "+v"(qn));
+    };
+    // Same, but pinned into the recurrence: the empty asm also "modifies" the running
+    // intensity, so the loads for layer s+kPF cannot be hoisted above layer s-1 (without this
+    // the scheduler issues dozens of layers of loads up front and spills the register file).
+    auto issue_after = [&](int slot, double &pin) {
+      asm volatile("" : "+v"(qn), "+v"(pin));
+      issue(slot);
+    };
+
+    if constexpr (NL > 0) {
+      pair_start(0);
+#pragma unroll
+      for (int s = 0; s < kPF; ++s) issue(s);
+    }
+
+    for (int it = 0; it < niter; ++it) {
+      const int gi = it / a.nmus, k = it - gi * a.nmus;
+      const int g = gi * GW + gs;
+      const bool gact = g < ng;
+      const int gg = gact ? g : ng - 1;
+      const long base = cc + (long)ncol * nlay * gg;
+      const double D = a.Ds[k];
+      const double wfac = gact ? 2. * pi * a.wts[k] : 0.;
+      const double eps = a.sfc_emis[a.gpt2band[gg] + (long)a.nband * cc];
+      const double sfc_src = a.sfc_source[cc + (long)ncol * gg];
+
+      // ---------------- down sweep ----------------
+      double I = 0.;   // no incident diffuse flux: radn_dn(top) = 0
+      auto layer = [&](int s, double tau, double lay, double bdn, double bup, double &t_out,
+                       double &su_out) {
+        const double tl = tau * D;
+        const double t = exp(-tl);
+        const double omt = 1. - t;
+        // both branches of lw_source_noscat's merge() are evaluated and selected (no branch)
+        const double fact_big = omt / tl - t;
+        const double fact_small = tl * (0.5 - 1. / 3. * tl);
+        const double fact = tl > tau_thresh ? fact_big : fact_small;
+        const double sdn = omt * bdn + 2. * fact * (lay - bdn);
+        double su = omt * bup + 2. * fact * (lay - bup);
+        // Materialise source_up here: left alone, the optimiser sinks this expression into the
+        // up sweep and keeps its five inputs alive per layer instead of the one result.
+        asm volatile("" : "+v"(su));
+        su_out = su;
+        t_out = t;
+        const double v = gsum<CW>(wfac * I);
+        acc_add(&acc_dn[s * CW + cl], v, owner);
+        I = t * I + sdn;
+      };
+      if constexpr (NL > 0) {
+#pragma unroll
+        for (int s = 0; s < NL; ++s) {
+          const double tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF],
+                       bup = pbup[s % kPF];
+          if (s + kPF < NL) issue_after(s % kPF, I);
+          layer(s, tau, lay, bdn, bup, T[s], SU[s]);
+          if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next pair's first layers start streaming while the up sweep runs from registers
+        if (it + 1 < niter) {
+          pair_start(it + 1);
+#pragma unroll
+          for (int s = 0; s < kPF; ++s) issue(s);
+        }
+      } else {
+        for (int s = 0; s < nlay; ++s) {
+          const long q = base + (long)ncol * (lay0 + lstep * s);
+          double t, su;
+          layer(s, a.tau[q], a.lay_source[q], Bdn[q], Bup[q], t, su);
+          sT[(long)s * 64] = t;
+          sSU[(long)s * 64] = su;
+        }
+      }
+      {
+        const double v = gsum<CW>(wfac * I);
+        acc_add(&acc_dn[nlay * CW + cl], v, owner);
+      }
+      // ---------------- surface + up sweep ----------------
+      double U = I * (1. - eps) + eps * sfc_src;
+      auto up = [&](int s, double t, double su) {
+        const double v = gsum<CW>(wfac * U);
+        acc_add(&acc_up[(s + 1) * CW + cl], v, owner);
+        U = t * U + su;
+      };
+      if constexpr (NL > 0) {
+#pragma unroll
+        for (int s = NL - 1; s >= 0; --s) up(s, T[s], SU[s]);
+      } else {
+        for (int s = nlay - 1; s >= 0; --s) up(s, sT[(long)s * 64], sSU[(long)s * 64]);
+      }
+      {
+        const double v = gsum<CW>(wfac * U);
+        acc_add(&acc_up[cl], v, owner);
+      }
+    }
+
+    // broadband fluxes: level s-th from the top -> lev0 + lstep*s
+    if (valid) {
+      for (int s = gs; s < nlev; s += GW) {
+        const long q = col + (long)ncol * (lev0 + lstep * s);
+        a.flux_dn[q] = acc_dn[s * CW + cl];
+        a.flux_up[q] = acc_up[s * CW + cl];
+      }
+    }
+  }
+}
+
+constexpr int kGenericWaves = 4096;
+
+template <int NL, int CW>
+hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
+  auto k = rte_lw_kernel<NL, CW>;
+  const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1) * CW;
+  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  long tiles = ((long)a.ncol + CW - 1) / CW;
+  if (NL == 0 && tiles > kGenericWaves) tiles = kGenericWaves;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
+  (void)ng;
+  if (nlay == 60) return 0;
+  long tiles = ((long)ncol + 15) / 16;
+  if (tiles > kGenericWaves) tiles = kGenericWaves;
+  return sizeof(double) * 2 * (size_t)nlay * 64 * (size_t)tiles;
+}
+
+hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
+  if (a.ncol <= 0) return hipSuccess;
+  static_assert(kPF <= 60, "prefetch ring deeper than the layer count");
+  if (a.nlay == 60) return launch_one<60, 16>(a, s);
+  return launch_one<0, 16>(a, s);
+}
+
+}  // namespace ecckd

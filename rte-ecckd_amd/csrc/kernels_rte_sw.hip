@@ -1,0 +1,183 @@
+// kernels_rte_sw.hip -- shortwave two-stream + adding flux solver with the broadband g-point
+// reduction fused in, and the toa_src broadcast of gas_optics_ext.
+//
+// Replaces RTE-RRTMGP's rte_sw as the reference calls it (example/rfmip-rad-irf/
+// ecckd_rfmip_sw.F90:148-154): sw_two_stream (Zdunkowski PIFM / Meador-Weaver), sw_source_2str,
+// adding, flux_dn = diffuse + direct, then ty_fluxes_broadband%reduce.
+//
+// Mapping (gfx950): as the LW solver -- one wave = CW columns x GW=64/CW g-points, lanes that
+// share a column are summed with a wave shuffle butterfly into wave-private LDS accumulators.
+// The adding method needs four per-layer quantities bottom-up and six top-down; round-1
+// version keeps them in a per-wave global scratch ring ([array][layer][lane], 512 B coalesced
+// rows) instead of registers.
+#include "kernels.hpp"
+
+namespace ecckd {
+namespace {
+
+template <int CW>
+__device__ __forceinline__ double gsum(double v) {
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kSwWaves = 2048;
+
+template <int CW>
+__global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
+  constexpr int GW = 64 / CW;
+  extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
+  const int lane = threadIdx.x;
+  const int cl = lane % CW, gs = lane / CW;
+  const int ncol = a.ncol, nlay = a.nlay, ng = a.ng, nlev = nlay + 1;
+  double *acc_up = acc, *acc_dn = acc + nlev * CW, *acc_dir = acc + 2 * nlev * CW;
+  const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
+  const long lstep = a.top_at_1 ? 1 : -1;
+  const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
+  // scratch ring of this wave: 4 layer arrays + 3 level arrays, each [index][64 lanes]
+  double *sc = a.scratch + (long)blockIdx.x * (4L * nlay + 3L * nlev) * 64 + lane;
+  double *sRdif = sc, *sTdif = sc + 64L * nlay, *sX = sc + 128L * nlay, *sSdn = sc + 192L * nlay;
+  double *sAlb = sc + 256L * nlay, *sSrc = sAlb + 64L * nlev, *sDir = sSrc + 64L * nlev;
+  const int ngroups = (ng + GW - 1) / GW;
+  const long ntiles = ((long)ncol + CW - 1) / CW;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long col = tile * CW + cl;
+    const bool valid = col < ncol;
+    const long cc = valid ? col : (long)ncol - 1;
+    for (int i = lane; i < 3 * nlev * CW; i += 64) acc[i] = 0.;
+    const double mu0 = a.mu0[cc];
+    const double mu0_inv = 1. / mu0;
+
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int g = gi * GW + gs;
+      const bool gact = g < ng;
+      const int gg = gact ? g : ng - 1;
+      const double keep = gact ? 1. : 0.;
+      const long base = cc + (long)ncol * nlay * gg;
+      const int band = a.gpt2band[gg];
+      const double alb_dir = a.alb_dir[band + (long)a.nband * cc];
+      const double alb_dif = a.alb_dif[band + (long)a.nband * cc];
+
+      // ---- pass 1, top -> bottom: two-stream coefficients, direct beam, sources ----
+      double fdir = a.toa[cc + (long)ncol * gg] * mu0;
+      for (int s = 0; s < nlay; ++s) {
+        const long q = base + (long)ncol * (lay0 + lstep * s);
+        const double tau = a.tau[q], w0 = a.ssa[q], gq = a.g[q];
+        const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
+        const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
+        const double gamma3 = (2. - 3. * mu0 * gq) * .25;
+        const double gamma4 = 1. - gamma3;
+        const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+        const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+        const double kk0 = (gamma1 - gamma2) * (gamma1 + gamma2);
+        const double k = sqrt(kk0 > 1.e-12 ? kk0 : 1.e-12);
+        const double exp_minusktau = exp(-tau * k);
+        const double exp_minus2ktau = exp_minusktau * exp_minusktau;
+        double RT_term = 1. / (k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
+        const double Rdif = RT_term * gamma2 * (1. - exp_minus2ktau);
+        const double Tdif = RT_term * 2. * k * exp_minusktau;
+        const double Tnoscat = exp(-tau * mu0_inv);
+        const double k_mu = k * mu0, k_gamma3 = k * gamma3, k_gamma4 = k * gamma4;
+        const double d = 1. - k_mu * k_mu;
+        RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
+        const double Rdir = RT_term * ((1. - k_mu) * (alpha2 + k_gamma3) -
+                                       (1. + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
+                                       2.0 * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * Tnoscat);
+        const double Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
+                                        (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * Tnoscat -
+                                        2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+        sRdif[64L * s] = Rdif;
+        sTdif[64L * s] = Tdif;
+        sX[64L * s] = Rdir * fdir;     // source_up
+        sSdn[64L * s] = Tdir * fdir;   // source_dn
+        sDir[64L * s] = fdir;
+        fdir = Tnoscat * fdir;
+      }
+      sDir[64L * nlay] = fdir;
+
+      // ---- pass 2, bottom -> top: adding (albedo and source of upward radiation) ----
+      double albedo = alb_dif, src = fdir * alb_dir;
+      sAlb[64L * nlay] = albedo;
+      sSrc[64L * nlay] = src;
+      for (int s = nlay - 1; s >= 0; --s) {
+        const double Rdif = sRdif[64L * s], Tdif = sTdif[64L * s];
+        const double src_up = sX[64L * s], src_dn = sSdn[64L * s];
+        const double denom = 1. / (1. - Rdif * albedo);
+        const double nalb = Rdif + Tdif * Tdif * albedo * denom;
+        src = src_up + Tdif * denom * (src + albedo * src_dn);
+        albedo = nalb;
+        sX[64L * s] = denom;   // source_up is no longer needed
+        sAlb[64L * s] = albedo;
+        sSrc[64L * s] = src;
+      }
+
+      // ---- pass 3, top -> bottom: fluxes ----
+      double fdn = 0.;
+      for (int s = 0; s <= nlay; ++s) {
+        if (s > 0)
+          fdn = (sTdif[64L * (s - 1)] * fdn + sRdif[64L * (s - 1)] * sSrc[64L * s] + sSdn[64L * (s - 1)]) *
+                sX[64L * (s - 1)];
+        const double fup = fdn * sAlb[64L * s] + sSrc[64L * s];
+        const double dir = sDir[64L * s];
+        const double vu = gsum<CW>(keep * fup), vd = gsum<CW>(keep * (fdn + dir)), vr = gsum<CW>(keep * dir);
+        if (gs == 0) {
+          acc_up[s * CW + cl] += vu;
+          acc_dn[s * CW + cl] += vd;
+          acc_dir[s * CW + cl] += vr;
+        }
+      }
+    }
+
+    if (valid) {
+      for (int s = gs; s < nlev; s += GW) {
+        const long q = col + (long)ncol * (lev0 + lstep * s);
+        a.flux_up[q] = acc_up[s * CW + cl];
+        a.flux_dn[q] = acc_dn[s * CW + cl];
+        if (a.flux_dir) a.flux_dir[q] = acc_dir[s * CW + cl];
+      }
+    }
+  }
+}
+
+__global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *toa) {
+  const long n = (long)ncol * ng;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x)
+    toa[q] = solar[q / ncol];   // src/gas_optics_ecckd.f90:468-472
+}
+
+}  // namespace
+
+size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
+  (void)ng;
+  long tiles = ((long)ncol + 15) / 16;
+  if (tiles > kSwWaves) tiles = kSwWaves;
+  return sizeof(double) * (size_t)(4L * nlay + 3L * (nlay + 1)) * 64 * (size_t)tiles;
+}
+
+hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
+  if (a.ncol <= 0) return hipSuccess;
+  constexpr int CW = 16;
+  auto k = rte_sw_kernel<CW>;
+  const size_t lds = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW;
+  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  long tiles = ((long)a.ncol + CW - 1) / CW;
+  if (tiles > kSwWaves) tiles = kSwWaves;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s) {
+  const long n = (long)ncol * ng;
+  if (n <= 0) return hipSuccess;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(toa_src_kernel, dim3((unsigned)blocks), dim3(256), 0, s, solar, ncol, ng, toa_src);
+  return hipGetLastError();
+}
+
+}  // namespace ecckd
