@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LW gas_optics + rte_lw throughput in Mcol*lay*gpt/s.
+
+One "step" = one pass of the hot path (ecckd_gas_optics_lw then ecckd_rte_lw, 1 quadrature
+angle, top_at_1, fp64) over `--ncol` synthetic columns x 60 layers x 32 g-points PER GPU, all
+inputs and the four (ncol,nlay,ngpt) intermediates resident in HBM.  Columns are independent, so
+N GPUs = N column ranges (rank r generates columns [r*ncol, (r+1)*ncol)), no data-path
+collective: weak scaling.  See DESIGN.md "Measurement".
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+LW_FILE = os.path.join(ROOT, "data", "ecckd-1.2_lw_ckd-definition_climate_fsck-tol0.0161.nc")
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+NLAY = 60
+
+
+def algorithmic_bytes_per_column(ng, nlay=NLAY):
+    """SURVEY.md §8(d) accounting at the API boundary (fp64), split per kernel.
+    tau kernel:    writes tau (8 B/cell); reads plev(61) tlay(60) h2o(60) o3(60) + 5 per-column vmr
+    planck kernel: writes lay_source, lev_source_inc, lev_source_dec (24 B/cell) + sfc_source;
+                   reads tlay(60) tlev(61) tsfc(1)
+    rte_lw kernel: reads the four 3-D arrays (32 B/cell) + sfc_source + emis; writes 2x61 fluxes"""
+    cells = nlay * ng
+    tau = 8 * cells + 8 * ((nlay + 1) + nlay + 2 * nlay + 5)
+    planck = 24 * cells + 8 * ng + 8 * (nlay + (nlay + 1) + 1)
+    rte = 32 * cells + 8 * ng + 8 + 8 * 2 * (nlay + 1)
+    return {"tau": tau, "planck": planck, "rte_lw": rte}
+
+
+def cpu_baseline(args, press_min):
+    """The CPU restatement (oracle/, 'port' of the reference Fortran: same per-gas passes and
+    temporaries as src/gas_optics_ecckd.f90:117-240,370 plus the RTE LW recurrences) timed on this
+    host's cores over a bounded sample of the same synthetic columns, column blocks spread over
+    OpenMP threads."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from rte_ecckd_amd import synthetic
+    m = oracle.CkdModel(LW_FILE)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    block = args.cpu_block
+    probe_n = 64 * cores
+    cols = synthetic.columns(0, probe_n, press_min)
+    t0 = time.perf_counter()
+    oracle.lw_pipeline(m, cols["plev"], cols["tlay"], cols["tlev"], cols["tsfc"], synthetic.gas_items(cols),
+                       cols["sfc_emis"], block=block, nthreads=cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(args.ncol, max(probe_n, probe_n * args.cpu_seconds / dt)))
+    n -= n % (block * cores) or 0
+    n = max(n, block * cores)
+    cols = synthetic.columns(0, n, press_min)
+    items = synthetic.gas_items(cols)
+    t0 = time.perf_counter()
+    oracle.lw_pipeline(m, cols["plev"], cols["tlay"], cols["tlev"], cols["tsfc"], items, cols["sfc_emis"],
+                       block=block, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n * NLAY * m.ng / dt / 1e6, "unit": "Mcol*lay*gpt/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic columns x %d layers x %d g-points, column blocks of %d over %d OpenMP "
+                      "threads, %.1f s" % (n, NLAY, m.ng, block, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncol", type=int, default=1000000, help="synthetic columns per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rte_ecckd_amd as pkg
+    from rte_ecckd_amd import synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    L = pkg.lib()
+    k = pkg.GasOpticsEcckd()
+    err = k.load(LW_FILE, device=local_rank)
+    if err:
+        raise SystemExit(err)
+    ng, ncol, nlay = k.get_ngpt(), args.ncol, NLAY
+    press_min = k.get_press_min()
+
+    # ---- synthetic inputs, generated in chunks on the host, resident on the device ----
+    f64 = dict(dtype=torch.float64, device=dev)
+    plev = torch.empty((nlay + 1, ncol), **f64)
+    tlev = torch.empty((nlay + 1, ncol), **f64)
+    tlay = torch.empty((nlay, ncol), **f64)
+    h2o = torch.empty((nlay, ncol), **f64)
+    o3 = torch.empty((nlay, ncol), **f64)
+    percol = {n: torch.empty((ncol,), **f64) for n in ("tsfc", "sfc_emis", "co2", "ch4", "n2o", "cfc11", "cfc12")}
+    chunk = 100000
+    for c0 in range(0, ncol, chunk):
+        n = min(chunk, ncol - c0)
+        cols = synthetic.columns(rank * ncol + c0, n, press_min)
+        for dst, key in ((plev, "plev"), (tlev, "tlev"), (tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
+            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+        for key, dst in percol.items():
+            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+    gc = pkg.GasConcs(synthetic.GAS_ORDER)
+    for name in synthetic.GAS_ORDER:
+        if name in ("h2o", "o3"):
+            gc.set_vmr(name, h2o if name == "h2o" else o3)
+        elif name in percol:
+            gc.set_vmr_column(name, percol[name])
+        else:
+            gc.set_vmr(name, 0.209 if name == "o2" else 0.0)
+    emis = percol["sfc_emis"].reshape(ncol, 1)
+
+    op = pkg.OpticalProps1scl()
+    op.alloc_1scl(ncol, nlay, k, like=plev)
+    src = pkg.SourceFuncLW()
+    src.alloc(ncol, nlay, k, like=plev)
+    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), **f64), torch.empty((nlay + 1, ncol), **f64))
+
+    def step():
+        e = k.gas_optics(None, plev, tlay, percol["tsfc"], gc, op, src, tlev=tlev)
+        if e:
+            raise SystemExit(e)
+        e = pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1)
+        if e:
+            raise SystemExit(e)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    L.ecckd_prof_enable(1)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.ecckd_prof_enable(0)
+
+    # per-kernel HIP-event durations recorded inside the timed region
+    names = C.create_string_buffer(8 * 32)
+    ms = (C.c_double * 8)()
+    cnt = (C.c_longlong * 8)()
+    nk = L.ecckd_prof_report(8, names, ms, cnt)
+    kern = {}
+    for i in range(nk):
+        kern[names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode()] = (ms[i] / max(cnt[i], 1), int(cnt[i]))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        cells_per_gpu = ncol * nlay * ng
+        value = world * cells_per_gpu * args.steps / elapsed / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        bpc = algorithmic_bytes_per_column(ng)
+        per_kernel = {}
+        for name, (avg_ms, n) in kern.items():
+            b = bpc.get(name, 0) * ncol
+            per_kernel[name] = {"avg_ms": avg_ms, "launches": n, "alg_bytes_per_launch": b,
+                                "GBps": b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}
+        dom = max(kern, key=lambda n: kern[n][0]) if kern else None
+        roofline = None
+        if dom:
+            ach = per_kernel[dom]["GBps"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": per_kernel[dom]["avg_ms"],
+                        "alg_bytes_per_launch": per_kernel[dom]["alg_bytes_per_launch"]}
+        total_b = sum(bpc.values()) * ncol
+        pipe = total_b / (ms_per_step * 1e-3) / 1e9
+        # spot check of the timed configuration against the CPU oracle (64 columns)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        m = oracle.CkdModel(LW_FILE)
+        cols = synthetic.columns(0, 64, press_min)
+        tau, lay, inc, dec, sfc, _ = oracle.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                           synthetic.gas_items(cols), cols["tlev"])
+        fu, fd = oracle.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None, :], ng, 0), sfc)
+        dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].cpu().numpy() - fu))),
+                    float(np.max(np.abs(fl.flux_dn[:, :64].cpu().numpy() - fd))))
+        out = {
+            "metric": "Mcol*lay*gpt/s LW gas_optics+rte_lw", "value": value, "unit": "Mcol*lay*gpt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %d columns x %d layers x %d g-points per GPU, LW fsck-tol0.0161, "
+                                   "gas_optics + rte_lw (1 angle), fp64, inputs and intermediates HBM-resident; "
+                                   "north_star target size (configs[1] is the same workload at 1e5 columns)"
+                                   % (ncol, nlay, ng),
+                       "ncol_per_gpu": ncol, "nlay": nlay, "ngpt": ng, "parallelism": "column-range x%d" % world},
+            "roofline": roofline,
+            "roofline_pipeline": {"bound": "hbm", "achieved": pipe, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": pipe / HBM_PEAK_GBS, "alg_bytes_per_cell": total_b / ncol / (nlay * ng),
+                                  "note": "all kernels of one step, per GPU"},
+            "kernels": per_kernel,
+            "check_max_abs_flux_diff_vs_oracle_Wm2": dflux,
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, press_min)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

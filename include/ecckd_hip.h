@@ -167,6 +167,16 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
                  int memspace, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Measurement hooks (no counterpart in the reference, which has no timers: SURVEY.md §5).
+ * While enabled, every kernel launch is bracketed by HIP events recorded on the stream the
+ * kernel is launched on.  ecckd_prof_report waits for the recorded events, sums the elapsed
+ * time per kernel name ("tau", "planck", "rte_lw", "rte_sw"), clears the records and returns
+ * the number of distinct kernels; names is max_kernels records of ECCKD_NAME_LEN bytes.
+ * --------------------------------------------------------------------------------------- */
+int ecckd_prof_enable(int on);
+int ecckd_prof_report(int max_kernels, char *names, double *total_ms, long long *launches);
+
 /* Library / build identification ("gfx950", compile flags); never NULL. */
 const char *ecckd_build_info(void);
 

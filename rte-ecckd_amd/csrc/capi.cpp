@@ -55,6 +55,30 @@ Arena g_scratch_arena[16];   // generic-nlay solver scratch (device flavours too
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (ecckd_prof_*) ----
+struct ProfRec { const char *name; hipEvent_t start, stop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+  hipStream_t s;
+  ProfRec r{};
+  bool on;
+  ProfScope(const char *name, hipStream_t stream) : s(stream), on(g_prof_on) {
+    if (!on) return;
+    r.name = name;
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.start, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.stop, s);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof.push_back(r);
+  }
+};
+
 // Bump allocator over an Arena block.
 struct Bump {
   char *base;
@@ -153,7 +177,10 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
       a.ssa = ssa;
       a.g = g;
     }
-    HIPCHK(launch_tau(a, stream));
+    {
+      ProfScope prof("tau", stream);
+      HIPCHK(launch_tau(a, stream));
+    }
     first_pass = false;
   } while (pos < seq.size());
   return 0;
@@ -226,6 +253,40 @@ const char *ecckd_last_error(void) { return g_err.c_str(); }
 
 const char *ecckd_build_info(void) {
   return "rte-ecckd hot path for MI355X: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, fp64";
+}
+
+// ------------------------------- kernel timing hooks -------------------------------------
+
+int ecckd_prof_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int ecckd_prof_report(int max_kernels, char *names, double *total_ms, long long *launches) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  int n = 0;
+  for (ProfRec &r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess) (void)hipEventElapsedTime(&ms, r.start, r.stop);
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+    int k = 0;
+    for (; k < n; ++k)
+      if (std::strncmp(names + (size_t)k * ECCKD_NAME_LEN, r.name, ECCKD_NAME_LEN) == 0) break;
+    if (k == n) {
+      if (n >= max_kernels) continue;
+      std::memset(names + (size_t)n * ECCKD_NAME_LEN, 0, ECCKD_NAME_LEN);
+      std::strncpy(names + (size_t)n * ECCKD_NAME_LEN, r.name, ECCKD_NAME_LEN - 1);
+      total_ms[n] = 0.;
+      launches[n] = 0;
+      ++n;
+    }
+    total_ms[k] += ms;
+    launches[k] += 1;
+  }
+  g_prof.clear();
+  return n;
 }
 
 // ------------------------------- model construction -------------------------------------
@@ -432,7 +493,10 @@ static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const dou
   p.tlay = tlay; p.tlev = tlev; p.tsfc = tsfc;
   p.lay_source = lay_source; p.lev_source_inc = lev_inc; p.lev_source_dec = lev_dec;
   p.sfc_source = sfc_source;
-  HIPCHK(ecckd::launch_planck(p, stream));                          // :407-424
+  {
+    ProfScope prof("planck", stream);
+    HIPCHK(ecckd::launch_planck(p, stream));                        // :407-424
+  }
   return 0;
 }
 
@@ -606,7 +670,10 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
     a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc;
     a.lev_source_dec = lev_source_dec; a.sfc_source = sfc_source; a.sfc_emis = sfc_emis;
     a.flux_up = flux_up; a.flux_dn = flux_dn;
-    HIPCHK(ecckd::launch_rte_lw(a, static_cast<hipStream_t>(stream)));
+    {
+      ProfScope prof("rte_lw", static_cast<hipStream_t>(stream));
+      HIPCHK(ecckd::launch_rte_lw(a, static_cast<hipStream_t>(stream)));
+    }
     if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // scratch is shared
     return 0;
   }
@@ -659,7 +726,10 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
     a.tau = tau; a.ssa = ssa; a.g = g; a.mu0 = mu0; a.toa = toa_flux;
     a.alb_dir = sfc_alb_dir; a.alb_dif = sfc_alb_dif;
     a.flux_up = flux_up; a.flux_dn = flux_dn; a.flux_dir = flux_dir;
-    HIPCHK(ecckd::launch_rte_sw(a, static_cast<hipStream_t>(stream)));
+    {
+      ProfScope prof("rte_sw", static_cast<hipStream_t>(stream));
+      HIPCHK(ecckd::launch_rte_sw(a, static_cast<hipStream_t>(stream)));
+    }
     if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return 0;
   }
