@@ -82,7 +82,8 @@ int ecckd_model_set_bands(ecckd_model_t *model, int nband, const double *band_li
 int ecckd_model_add_gas(ecckd_model_t *model, const char *name, int concentration_dependence_code,
                         int composite_only, int nv, const double *mole_fraction,
                         double reference_mole_fraction, const double *coefficient);
-/* Upload the tables to GPU `device` (HIP ordinal) and freeze the model. */
+/* Upload the tables to GPU `device` (HIP ordinal) and freeze the model.  device == -1 makes a
+ * host-only model (also accepted by ecckd_model_load): the getters work, compute calls fail. */
 int ecckd_model_finalize(ecckd_model_t *model, int device);
 void ecckd_model_destroy(ecckd_model_t *model);
 

@@ -189,6 +189,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
 int check_model(const ecckd_model *m) {
   if (!m) return fail("ecckd: null model");
   if (!m->finalized) return fail("ecckd: model is not finalized");
+  if (m->device < 0) return fail("ecckd: host-only model (device -1): no GPU, no compute (there is no CPU fallback)");
   return 0;
 }
 
@@ -369,6 +370,11 @@ int ecckd_model_add_gas(ecckd_model_t *m, const char *name, int code, int compos
 int ecckd_model_finalize(ecckd_model_t *m, int device) {
   if (!m) return fail("ecckd_model_finalize: null model");
   if (m->finalized) return fail("ecckd_model_finalize: already finalized");
+  if (device == -1) {   // host-only model: getters work, every compute call fails
+    m->device = -1;
+    m->finalized = true;
+    return 0;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail("ecckd: no HIP device available (this library has no CPU fallback)");
@@ -429,7 +435,7 @@ int ecckd_model_load(const char *filename, int device, ecckd_model_t **model) {
 
 void ecckd_model_destroy(ecckd_model_t *m) {
   if (!m) return;
-  if (m->finalized) {
+  if (m->finalized && m->device >= 0) {
     (void)hipSetDevice(m->device);
     if (m->host_stream) (void)hipStreamDestroy(m->host_stream);
     if (m->arena) (void)hipFree(m->arena);

@@ -1,0 +1,128 @@
+"""CPU tests of the host side: the C ABI library loads and exports everything the header
+declares, load() (= load_and_init) agrees with the Python restatement of the reference's loader,
+error behaviour, and -- the important one -- nothing computes without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from conftest import LW_FSCK, LW_RRTMGP, SW_WIDE
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    syms = entry.exported_symbols()
+    assert "ecckd_gas_optics_lw" in syms and "ecckd_rte_sw" in syms and len(syms) >= 28
+    for s in syms:
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.ecckd_build_info()
+
+
+@pytest.mark.parametrize("path", [LW_FSCK, LW_RRTMGP, SW_WIDE])
+def test_load_matches_reference_loader_restatement(pkg, oracle_mod, path):
+    """Own CDF-1 reader + load_and_init (C++) vs scipy + the Python restatement."""
+    k = pkg.GasOpticsEcckd()
+    assert k.load(path, device=-1) == ""          # host-only model: no GPU needed for getters
+    m = oracle_mod.CkdModel(path)
+    assert k.get_ngpt() == m.ng
+    assert k.get_ngas() == m.num_gases and k.get_gases() == m.gas
+    assert k.get_nband() == m.band2gpt.shape[0]
+    assert np.array_equal(k.get_band2gpt(), m.band2gpt)
+    assert np.array_equal(k.get_band_lims_wavenumber(), m.band_lims_wvn)
+    assert k.source_is_internal() == (not m.shortwave) and k.source_is_external() == m.shortwave
+    assert k.get_press_min() == float(np.exp(m.log_pressure[0]))
+    assert k.get_press_max() == float(np.exp(m.log_pressure[-1]))
+    assert k.get_temp_min() == float(m.temperature.min()) and k.get_temp_max() == float(m.temperature.max())
+    if m.shortwave:
+        assert k.get_total_solar_irradiance() == m.total_solar_irradiance
+    k.finalize()
+
+
+def test_load_errors(pkg, tmp_path):
+    k = pkg.GasOpticsEcckd()
+    assert "can't open file" in k.load(str(tmp_path / "nope.nc"), device=-1)
+    bad = tmp_path / "bad.nc"
+    bad.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    assert "not a netCDF-3" in k.load(str(bad), device=-1)
+    trunc = tmp_path / "trunc.nc"
+    trunc.write_bytes(open(LW_FSCK, "rb").read()[:3000])
+    assert k.load(str(trunc), device=-1) != ""
+
+
+def test_cdf2_and_small_model_roundtrip(pkg, oracle_mod, tmp_path):
+    """A tiny ecCKD-style file written as 64-bit-offset netCDF (CDF-2) goes through the same loader."""
+    from scipy.io import netcdf_file
+    p = str(tmp_path / "tiny.nc")
+    f = netcdf_file(p, "w", version=2)
+    for n, d in (("temperature", 3), ("pressure", 4), ("g_point", 2), ("temperature_planck", 5),
+                 ("wavenumber", 3), ("band", 1), ("x_mole_fraction", 2)):
+        f.createDimension(n, d)
+    v = f.createVariable("pressure", "f4", ("pressure",)); v[:] = [10., 100., 1000., 10000.]
+    v = f.createVariable("temperature", "f4", ("temperature", "pressure")); v[:] = np.arange(12).reshape(3, 4) + 200
+    v = f.createVariable("temperature_planck", "f4", ("temperature_planck",)); v[:] = [100, 150, 200, 250, 300]
+    v = f.createVariable("planck_function", "f4", ("temperature_planck", "g_point")); v[:] = np.arange(10).reshape(5, 2)
+    v = f.createVariable("gpoint_fraction", "f4", ("g_point", "wavenumber")); v[:] = 0.5
+    v = f.createVariable("wavenumber1_band", "f4", ("band",)); v[:] = [0.]
+    v = f.createVariable("wavenumber2_band", "f4", ("band",)); v[:] = [3000.]
+    v = f.createVariable("band_number", "i2", ("g_point",)); v[:] = [0, 0]
+    v = f.createVariable("x_mole_fraction", "f4", ("x_mole_fraction",)); v[:] = [1e-6, 1e-5]
+    v = f.createVariable("x_molar_absorption_coeff", "f4", ("x_mole_fraction", "temperature", "pressure", "g_point"))
+    v[:] = np.arange(48).reshape(2, 3, 4, 2)
+    v = f.createVariable("y_conc_dependence_code", "i2", ()); v.data[...] = 3
+    v = f.createVariable("y_reference_mole_fraction", "f4", ()); v.data[...] = 4e-7
+    v = f.createVariable("y_molar_absorption_coeff", "f4", ("temperature", "pressure", "g_point")); v[:] = 1.0
+    f.constituent_id = "x yy"       # "yy" does not exist ...
+    f.close()
+    k = pkg.GasOpticsEcckd()
+    assert "yy" in k.load(p, device=-1)        # ... so the loader reports the missing variable
+    f = netcdf_file(p, "a"); f.constituent_id = "x y z"; f.close()   # last single-char token is dropped
+    assert open(p, "rb").read(4) == b"CDF\x02"
+    assert k.load(p, device=-1) == ""
+    assert k.get_gases() == ["x", "y"] and k.get_ngpt() == 2 and k.get_nband() == 1
+    assert oracle_mod.CkdModel(p).gas == ["x", "y"]
+
+
+def test_no_gpu_means_error_not_fallback(pkg):
+    """On a machine without a GPU every compute entry point must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU behaviour test")
+    k = pkg.GasOpticsEcckd()
+    err = k.load(LW_FSCK, device=0)
+    assert "no HIP device" in err and "no CPU fallback" in err
+    assert k.load(LW_FSCK, device=-1) == ""
+    nlay, ncol, ng = 60, 4, 32
+    gc = pkg.GasConcs(["h2o"]); gc.set_vmr("h2o", 1e-3)
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k)
+    src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k)
+    op.tau[:] = -7.0
+    err = k.gas_optics(None, np.full((nlay + 1, ncol), 1e4), np.full((nlay, ncol), 250.), np.full(ncol, 280.),
+                       gc, op, src, tlev=np.full((nlay + 1, ncol), 250.))
+    assert "no CPU fallback" in err
+    assert np.all(op.tau == -7.0)             # untouched: nothing was computed anywhere
+    fl = pkg.FluxesBroadband(np.zeros((nlay + 1, ncol)), np.zeros((nlay + 1, ncol)))
+    assert "no HIP device" in pkg.rte_lw(op, True, src, np.ones((ncol, 1)), fl)
+
+
+def test_gas_concs_mirror(pkg):
+    gc = pkg.GasConcs()
+    assert gc.init(["H2O ", "co2"]) == ""
+    assert gc.get_gas_names() == ["h2o", "co2"] and gc.get_num_gases() == 2
+    assert "name not provided" in gc.set_vmr("o3", 1e-6)
+    assert "should be >= 0" in gc.set_vmr("co2", -1.0)
+    assert gc.set_vmr("co2", 4e-4) == ""
+    with pytest.raises(KeyError):
+        gc.entries(3, 2)                       # h2o never set -> get_vmr error
+    assert gc.set_vmr("h2o", np.full((2, 3), 1e-3)) == ""
+    e = gc.entries(3, 2)
+    assert e[0][2:4] == (1, 3) and e[1][1] is None and e[1][4] == 4e-4
+    assert "duplicate" in gc.init(["a", "a"])
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_FSCK, device=-1) == ""
+    g2 = pkg.GasConcs(["h2o", "co2"]); g2.set_vmr("co2", 4e-4)
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(3, 2, k)
+    src = pkg.SourceFuncLW(); src.alloc(3, 2, k)
+    msg = k.gas_optics(None, np.ones((3, 3)), np.ones((2, 3)), np.ones(3), g2, op, src, tlev=np.ones((3, 3)))
+    assert msg == "ty_gas_concs%get_vmr; gas h2o not found"     # get_vmr error is passed through (:351-354)

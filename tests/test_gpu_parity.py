@@ -1,0 +1,349 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Stated tolerances (north_star: fluxes within 1e-6 W m-2 in fp64):
+
+  Planck sources (lay/lev/sfc)   bit-identical   (no transcendental on the path)
+  tau, ssa                       relative 1e-12  (the only difference is device log() vs libm)
+  broadband fluxes               absolute 1e-9 W m-2 (device exp(), g-point summation order)
+"""
+import numpy as np
+import pytest
+
+import helpers
+from conftest import LW_FSCK, LW_RRTMGP, SW_WIDE
+from rte_ecckd_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+TAU_RTOL = 1e-12
+FLUX_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def lw(pkg, gpu, oracle_mod):
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_FSCK, device=0) == ""
+    return k, oracle_mod.CkdModel(LW_FSCK)
+
+
+def edge_columns(press_min, ncol=96):
+    """Synthetic columns pushed through every branch of the gas optics."""
+    c = synthetic.columns(1000, ncol, press_min)
+    c = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    c["h2o"][:, 0:8] = 1e-9                       # below the first h2o LUT node
+    c["h2o"][:, 8:12] = 0.2                       # above the last node
+    c["ch4"][12:20] = 1e-7                        # below reference -> negative -> clamped
+    c["n2o"][12:20] = 1e-8
+    c["tlev"][:, 20:24] = 100.0; c["tlay"][:, 20:24] = 100.0; c["tsfc"][20:24] = 110.0   # below Planck table
+    c["tlev"][:, 24:28] = 400.0; c["tlay"][:, 24:28] = 400.0; c["tsfc"][24:28] = 360.0   # above it (extrapolates)
+    c["plev"][:, 28:32] *= 1e-3                   # far below the pressure grid
+    c["plev"][:, 32:36] *= 3.0                    # above it
+    c["plev"][:, 36:40] *= np.linspace(0.3, 1.0, 4)[None, :]   # wide pressure spread inside one tile
+    c["tlay"][:, 40:44] += 80.0                   # outside the 6-node T grid
+    c["tlay"][:, 44:48] -= 80.0
+    c["cfc11"][48:52] = 0.0
+    return c
+
+
+def check_lw(pkg, k, m, oracle_mod, cols, device, names=None, overrides=None):
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, device, names, overrides)
+    assert err == ""
+    otau, olay, oinc, odec, osfc, oerr = oracle_mod.gas_optics_int(
+        m, cols["plev"], cols["tlay"], cols["tsfc"], helpers.oracle_gas_items(cols, names, overrides), cols["tlev"])
+    assert oerr == ""
+    assert np.array_equal(lay, olay) and np.array_equal(inc, oinc) and np.array_equal(dec, odec)
+    assert np.array_equal(sfc, osfc)
+    assert helpers.max_rel(tau, otau) < TAU_RTOL
+    assert np.array_equal(tau == 0, otau == 0)     # clamped cells are exactly zero on both sides
+    return tau, lay, inc, dec, sfc, (otau, olay, oinc, odec, osfc)
+
+
+@pytest.mark.parametrize("ncol", [1, 63, 64, 65, 513, 1500])
+def test_lw_gas_optics_ragged_sizes(pkg, gpu, oracle_mod, lw, ncol):
+    k, m = lw
+    check_lw(pkg, k, m, oracle_mod, synthetic.columns(7, ncol, k.get_press_min()), gpu)
+
+
+def test_lw_gas_optics_edge_branches(pkg, gpu, oracle_mod, lw):
+    k, m = lw
+    check_lw(pkg, k, m, oracle_mod, edge_columns(k.get_press_min()), gpu)
+
+
+def test_lw_gas_lists(pkg, gpu, oracle_mod, lw):
+    """gas_desc order, unknown gases, composite-once, missing composite (src/gas_optics_ecckd.f90:348-374)."""
+    k, m = lw
+    cols = synthetic.columns(0, 70, k.get_press_min())
+    base = check_lw(pkg, k, m, oracle_mod, cols, gpu)[0]
+    rev = list(reversed(synthetic.GAS_ORDER))
+    t_rev = check_lw(pkg, k, m, oracle_mod, cols, gpu, names=rev)[0]
+    assert helpers.max_rel(t_rev, base) < 1e-13     # different summation order, same physics
+    with_n2 = synthetic.GAS_ORDER + ["n2"]
+    t_n2 = check_lw(pkg, k, m, oracle_mod, cols, gpu, names=with_n2, overrides={"n2": 0.78})[0]
+    assert np.array_equal(t_n2, base)               # composite table counted once
+    no_comp = [g for g in synthetic.GAS_ORDER if g != "o2"]
+    t_nc = check_lw(pkg, k, m, oracle_mod, cols, gpu, names=no_comp)[0]
+    assert np.all(t_nc <= base) and np.any(t_nc < base)
+    only_unknown = check_lw(pkg, k, m, oracle_mod, cols, gpu, names=["no2", "xyz"], overrides={"xyz": 0.5})[0]
+    assert np.all(only_unknown == 0)
+    prof = {"co2": np.linspace(3e-4, 5e-4, 60)}     # a (nlay) profile, as ty_gas_concs allows
+    check_lw(pkg, k, m, oracle_mod, cols, gpu, overrides=prof)
+
+
+def test_host_and_device_memspace_agree(pkg, gpu, lw):
+    k, _ = lw
+    cols = synthetic.columns(3, 130, k.get_press_min())
+    d = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    h = helpers.run_lw_gas_optics(pkg, k, cols, None)
+    assert d[0] == h[0] == ""
+    for a, b in zip(d[1:], h[1:]):
+        assert np.array_equal(a, b)
+
+
+def test_tlev_required_error_behaviour(pkg, gpu, oracle_mod, lw):
+    """:414-417 -- tau, lay_source and sfc_source are produced, then the call fails."""
+    k, m = lw
+    cols = synthetic.columns(0, 40, k.get_press_min())
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu, tlev=False)
+    assert err == "tlev is required for ecckd"
+    ok = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    assert np.array_equal(tau, ok[1]) and np.array_equal(lay, ok[2]) and np.array_equal(sfc, ok[5])
+
+
+def test_builder_route_equals_load_route(pkg, gpu, oracle_mod, lw):
+    """ecckd_model_begin/_add_gas/_finalize (filling the type's members) == ecckd_model_load."""
+    k, m = lw
+    gases = [dict(name=n, code=t["code"], composite_only=int(t["composite_only"]), mole_fraction=t["mole_fraction"],
+                  reference_mole_fraction=t["reference_mole_fraction"],
+                  coefficient=t["coefficient"] if t["code"] == 2 else t["coefficient"][0])
+             for n, t in zip(m.gas, m.tables)]
+    k2 = pkg.GasOpticsEcckd()
+    assert k2.init_from_tables(m.log_pressure, m.temperature, gases,
+                               planck=(m.temperature_planck, m.planck_function)) == ""
+    assert k2.get_gases() == k.get_gases() and k2.get_ngpt() == 32
+    cols = synthetic.columns(11, 100, k.get_press_min())
+    a = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    b = helpers.run_lw_gas_optics(pkg, k2, cols, gpu)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
+def test_two_lut_gases_and_negative_tables(pkg, gpu, oracle_mod, lw):
+    """A model with two look_up_table gases (second kernel pass, accumulate) and a table with
+    negative coefficients (per-g clamp variant)."""
+    k, m = lw
+    rng = np.random.default_rng(5)
+    tabs = []
+    for n, t in zip(m.gas[:4], m.tables[:4]):
+        tabs.append(dict(name=n, code=t["code"], composite_only=0, mole_fraction=t["mole_fraction"],
+                         reference_mole_fraction=t["reference_mole_fraction"],
+                         coefficient=t["coefficient"] if t["code"] == 2 else t["coefficient"][0]))
+    h2o = m.tables[0]
+    tabs.append(dict(name="h2o_b", code=2, composite_only=0, mole_fraction=h2o["mole_fraction"] * 0.5,
+                     reference_mole_fraction=0.0, coefficient=h2o["coefficient"] * 0.25))
+    neg = m.tables[2]["coefficient"][0] * rng.choice([1.0, -1.0], size=m.tables[2]["coefficient"][0].shape)
+    tabs.append(dict(name="weird", code=1, composite_only=0, mole_fraction=None, reference_mole_fraction=0.0,
+                     coefficient=neg))
+    k2 = pkg.GasOpticsEcckd()
+    assert k2.init_from_tables(m.log_pressure, m.temperature, tabs,
+                               planck=(m.temperature_planck, m.planck_function)) == ""
+
+    class M2:   # oracle-side twin of the same tables
+        pass
+    m2 = oracle_mod.CkdModel(LW_FSCK)
+    m2.gas = [t["name"] for t in tabs]
+    m2.tables = [dict(code=t["code"], composite_only=False, mole_fraction=None if t["mole_fraction"] is None else np.ascontiguousarray(t["mole_fraction"], dtype=np.float64),
+                      reference_mole_fraction=t["reference_mole_fraction"],
+                      coefficient=np.ascontiguousarray(t["coefficient"] if t["coefficient"].ndim == 4 else t["coefficient"][None]),
+                      nv=t["coefficient"].shape[0] if t["coefficient"].ndim == 4 else 1) for t in tabs]
+    m2.num_gases = len(tabs)
+    cols = synthetic.columns(21, 200, k.get_press_min())
+    names = ["co2", "h2o", "weird", "h2o_b", "o3", "ch4"]
+    over = {"weird": 1e-4, "h2o_b": cols["h2o"] * 0.5}
+    check_lw(pkg, k2, m2, oracle_mod, cols, gpu, names=names, overrides=over)
+
+
+@pytest.mark.parametrize("nmus", [1, 2, 3, 4])
+def test_rte_lw_vs_oracle(pkg, gpu, oracle_mod, lw, nmus):
+    import torch
+    k, m = lw
+    cols = edge_columns(k.get_press_min(), 150)
+    tau, lay, inc, dec, sfc, o = check_lw(pkg, k, m, oracle_mod, cols, gpu)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = k.get_band2gpt()
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    ncol = tau.shape[2]
+    fl = pkg.FluxesBroadband(torch.empty((61, ncol), dtype=torch.float64, device=gpu),
+                             torch.empty((61, ncol), dtype=torch.float64, device=gpu))
+    assert pkg.rte_lw(op, True, src, t(cols["sfc_emis"][:, None]), fl, n_gauss_angles=nmus) == ""
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], 32, 0), sfc, nmus=nmus)
+    ok = np.isfinite(fu)   # columns pushed outside the tables may overflow identically on both sides
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)[ok]) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)[ok]) < FLUX_ATOL
+    assert np.all(fl.flux_dn.cpu().numpy()[0] == 0)
+    assert pkg.rte_lw(op, True, src, t(cols["sfc_emis"][:, None]), fl, n_gauss_angles=5) != ""
+
+
+@pytest.mark.parametrize("nlay,top_at_1", [(60, False), (5, True), (61, True), (91, False)])
+def test_rte_lw_other_layer_counts_and_orientation(pkg, gpu, oracle_mod, nlay, top_at_1):
+    """nlay != 60 takes the any-nlay solver path; top_at_1 = .false. walks the arrays backwards."""
+    import torch
+    rng = np.random.default_rng(nlay)
+    ng, ncol = 7, 77
+    tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (ng, ncol))
+    emis = rng.uniform(0.7, 1.0, (ncol, 2))
+    b2g = np.array([[1, 3], [4, 7]], dtype=np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = b2g
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu),
+                             torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu))
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl) == ""
+    emis_gpt = np.stack([emis[:, 0]] * 3 + [emis[:, 1]] * 4)
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, emis_gpt, sfc, top_at_1=top_at_1)
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+    # host memspace gives the same numbers
+    fl2 = pkg.FluxesBroadband(np.empty((nlay + 1, ncol)), np.empty((nlay + 1, ncol)))
+    op2 = pkg.OpticalProps1scl(); op2.tau = tau; op2.band2gpt = b2g
+    s2 = pkg.SourceFuncLW(); s2.lay_source, s2.lev_source_inc, s2.lev_source_dec, s2.sfc_source = lay, inc, dec, sfc
+    assert pkg.rte_lw(op2, top_at_1, s2, np.ascontiguousarray(emis), fl2) == ""
+    assert np.array_equal(fl2.flux_up, fl.flux_up.cpu().numpy())
+
+
+def test_lw_36g_16band_model(pkg, gpu, oracle_mod):
+    """The higher-g-point LW file present in the reference (rrtmgp-tol0.061: 36 g, 16 bands)."""
+    import torch
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_RRTMGP, device=0) == ""
+    m = oracle_mod.CkdModel(LW_RRTMGP)
+    cols = synthetic.columns(5, 300, k.get_press_min())
+    tau, lay, inc, dec, sfc, _ = check_lw(pkg, k, m, oracle_mod, cols, gpu)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = k.get_band2gpt()
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    emis = np.random.default_rng(0).uniform(0.9, 1.0, (300, 16))
+    fl = pkg.FluxesBroadband(torch.empty((61, 300), dtype=torch.float64, device=gpu),
+                             torch.empty((61, 300), dtype=torch.float64, device=gpu))
+    assert pkg.rte_lw(op, True, src, t(emis), fl) == ""
+    emis_gpt = emis[:, m.gpt2band - 1].T
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, np.ascontiguousarray(emis_gpt), sfc)
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+
+
+def test_sw_gas_optics_and_rte_sw(pkg, gpu, oracle_mod):
+    import torch
+    k = pkg.GasOpticsEcckd()
+    assert k.load(SW_WIDE, device=0) == ""
+    m = oracle_mod.CkdModel(SW_WIDE)
+    ncol, nlay, ng = 333, 60, 27
+    cols = synthetic.columns(9, ncol, k.get_press_min(), shortwave=True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    names = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
+    gc = helpers.product_gas_concs(pkg, cols, t, names)
+    op = pkg.OpticalProps2str(); op.alloc_2str(ncol, nlay, k, like=t(np.zeros(1)))
+    toa = torch.empty((ng, ncol), dtype=torch.float64, device=gpu)
+    assert k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), gc, op, toa) == ""
+    otau, ossa, og, otoa, oerr = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"],
+                                                           helpers.oracle_gas_items(cols, names))
+    assert oerr == ""
+    assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
+    assert helpers.max_rel(op.ssa.cpu().numpy(), ossa) < TAU_RTOL
+    assert np.all(op.g.cpu().numpy() == 0) and np.array_equal(toa.cpu().numpy(), otoa)
+    # one-stream optical props -> the reference's error, after tau has been written (:457-464)
+    op1 = pkg.OpticalProps1scl(); op1.alloc_1scl(ncol, nlay, k, like=t(np.zeros(1)))
+    assert k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), gc, op1, toa) == "shortwave must use ty_optical_props_2str"
+    assert np.array_equal(op1.tau.cpu().numpy(), op.tau.cpu().numpy())
+    # solver on the oracle's optical properties (isolates the solver), 5 bands of albedo
+    rng = np.random.default_rng(2)
+    alb_dir = rng.uniform(0.05, 0.4, (ncol, 5)); alb_dif = rng.uniform(0.05, 0.4, (ncol, 5))
+    op.tau, op.ssa, op.g = t(otau), t(ossa), t(og)
+    fl = pkg.FluxesBroadband(*(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3)))
+    assert pkg.rte_sw(op, True, t(cols["mu0"]), toa, t(alb_dir), t(alb_dif), fl) == ""
+    g2b = m.gpt2band - 1
+    fu, fd, fdir = oracle_mod.rte_sw(otau, ossa, og, cols["mu0"], otoa, np.ascontiguousarray(alb_dir[:, g2b].T),
+                                     np.ascontiguousarray(alb_dif[:, g2b].T))
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn_dir.cpu().numpy() - fdir)) < FLUX_ATOL
+    # bottom-at-1 orientation
+    f = lambda a: np.ascontiguousarray(a[:, ::-1, :])
+    op.tau, op.ssa, op.g = t(f(otau)), t(f(ossa)), t(f(og))
+    assert pkg.rte_sw(op, False, t(cols["mu0"]), toa, t(alb_dir), t(alb_dif), fl) == ""
+    assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)) < FLUX_ATOL
+
+
+def test_golden_fixture_on_gpu(pkg, gpu, lw):
+    """HIP path vs the committed golden vectors (tests/golden/lw_fsck_synth16.npz)."""
+    import os
+    import torch
+    k, _ = lw
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lw_fsck_synth16.npz"))
+    cols = synthetic.columns(0, 16, k.get_press_min())
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    assert err == ""
+    assert np.array_equal(lay, z["lay_source"]) and np.array_equal(inc, z["lev_source_inc"])
+    assert np.array_equal(sfc, z["sfc_source"])
+    assert helpers.max_rel(tau, z["tau"]) < TAU_RTOL
+
+
+def test_full_size_properties(pkg, gpu, oracle_mod, lw):
+    """BASELINE config 2 size (1e5 columns x 60 x 32): oracle spot checks at both ends, column
+    independence (a shuffled batch gives the shuffled answer, bit for bit), exact linearity of
+    rte_lw in the sources, zero incident flux at the top, and determinism."""
+    import torch
+    k, m = lw
+    ncol, nlay, ng = 100000, 60, 32
+    cols = synthetic.columns(0, ncol, k.get_press_min())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    dcols = {n: (t(v) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+
+    def run(dc, scale=1.0):
+        gc = pkg.GasConcs(synthetic.GAS_ORDER)
+        for n in synthetic.GAS_ORDER:
+            v = dc[n]
+            if not torch.is_tensor(v):
+                gc.set_vmr(n, float(v))
+            elif v.ndim == 1:
+                gc.set_vmr_column(n, v)
+            else:
+                gc.set_vmr(n, v)
+        op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=dc["plev"])
+        src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k, like=dc["plev"])
+        assert k.gas_optics(None, dc["plev"], dc["tlay"], dc["tsfc"], gc, op, src, tlev=dc["tlev"]) == ""
+        if scale != 1.0:
+            for a in (src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source):
+                a.mul_(scale)
+        fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu),
+                                 torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu))
+        assert pkg.rte_lw(op, True, src, dc["sfc_emis"].reshape(ncol, 1), fl) == ""
+        torch.cuda.synchronize()
+        return op, src, fl
+
+    op, src, fl = run(dcols)
+    for sl in (slice(0, 128), slice(ncol - 128, ncol)):
+        sub = {n: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+        otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, sub["plev"], sub["tlay"], sub["tsfc"],
+                                                                    synthetic.gas_items(sub), sub["tlev"])
+        fu, fd = oracle_mod.rte_lw(otau, olay, oinc, odec, np.repeat(sub["sfc_emis"][None], ng, 0), osfc)
+        assert helpers.max_rel(op.tau[..., sl].cpu().numpy(), otau) < TAU_RTOL
+        assert np.array_equal(src.lev_source_inc[..., sl].cpu().numpy(), oinc)
+        assert np.max(np.abs(fl.flux_up[:, sl].cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fl.flux_dn[:, sl].cpu().numpy() - fd)) < FLUX_ATOL
+    assert bool(torch.all(fl.flux_dn[0] == 0))
+    assert bool(torch.all(fl.flux_up > 0)) and bool(torch.all(torch.isfinite(fl.flux_up)))
+    # determinism
+    op2, src2, fl2 = run(dcols)
+    assert torch.equal(fl2.flux_up, fl.flux_up) and torch.equal(op2.tau, op.tau)
+    # column independence: permute the batch
+    perm = torch.randperm(ncol, device=gpu, generator=torch.Generator(device=gpu).manual_seed(1))
+    pc = {n: (v[..., perm].contiguous() if torch.is_tensor(v) else v) for n, v in dcols.items()}
+    op3, src3, fl3 = run(pc)
+    assert torch.equal(fl3.flux_up, fl.flux_up[:, perm]) and torch.equal(fl3.flux_dn, fl.flux_dn[:, perm])
+    assert torch.equal(op3.tau, op.tau[..., perm])
+    # linearity in the sources: x2 is exact in binary floating point
+    _, _, fl4 = run(dcols, scale=2.0)
+    assert torch.equal(fl4.flux_up, 2.0 * fl.flux_up) and torch.equal(fl4.flux_dn, 2.0 * fl.flux_dn)
