@@ -169,10 +169,23 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  int memspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Arithmetic mode of gas_optics (process-wide).
+ *   0 (default) fast: one fused kernel per call; the interpolation weights of a cell are
+ *               multiplied out once and each coefficient costs one FMA.  Same formula as
+ *               src/gas_optics_ecckd.f90:167-221, re-associated: tau differs from mode 1 by a
+ *               few ulp.  Planck sources are identical in both modes.
+ *   1           reference order: every product and sum in the order the Fortran expressions
+ *               spell, no FMA contraction, gases accumulated in gas_desc order (:370).  tau then
+ *               differs from an IEEE evaluation of the reference only through the device log().
+ * --------------------------------------------------------------------------------------- */
+int ecckd_set_arithmetic(int mode);
+int ecckd_get_arithmetic(void);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement hooks (no counterpart in the reference, which has no timers: SURVEY.md §5).
  * While enabled, every kernel launch is bracketed by HIP events recorded on the stream the
  * kernel is launched on.  ecckd_prof_report waits for the recorded events, sums the elapsed
- * time per kernel name ("tau", "planck", "rte_lw", "rte_sw"), clears the records and returns
+ * time per kernel name ("gas_lw_fused", "tau", "planck", "rte_lw", "rte_sw"), clears the records and returns
  * the number of distinct kernels; names is max_kernels records of ECCKD_NAME_LEN bytes.
  * --------------------------------------------------------------------------------------- */
 int ecckd_prof_enable(int on);

@@ -29,11 +29,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "librte_ecckd_hip.so")
+LIB_PATH = os.environ.get("ECCKD_LIB", os.path.join(_HERE, "librte_ecckd_hip.so"))   # override: kernel experiments
 HOST, DEVICE = 0, 1
 NAME_LEN = 32
 
-_SOURCES = ["kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_sw.hip",
+_SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_sw.hip",
             "capi.cpp", "model.cpp", "cdf1.cpp"]
 _HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -92,6 +92,20 @@ def lib():
 
 def last_error():
     return lib().ecckd_last_error().decode()
+
+
+FAST, REFERENCE_ORDER = 0, 1
+
+
+def set_arithmetic(mode):
+    """0 = fast (fused kernel, re-associated FMAs; default), 1 = reference expression order
+    (bit-faithful kernels); see ecckd_set_arithmetic in include/ecckd_hip.h."""
+    if lib().ecckd_set_arithmetic(int(mode)):
+        raise ValueError(last_error())
+
+
+def get_arithmetic():
+    return lib().ecckd_get_arithmetic()
 
 
 # ------------------------------------------------------------------------------------------

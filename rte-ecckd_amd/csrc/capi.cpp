@@ -55,6 +55,10 @@ Arena g_scratch_arena[16];   // generic-nlay solver scratch (device flavours too
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// Arithmetic mode (ecckd_set_arithmetic): 0 = fast (fused kernel, re-associated FMAs),
+// 1 = reference order (kernels_tau.hip + kernels_planck.hip, bit-faithful expression order).
+int g_arith = 0;
+
 // ---- optional per-kernel timing with HIP events on the launch stream (ecckd_prof_*) ----
 struct ProfRec { const char *name; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
@@ -105,12 +109,20 @@ size_t vmr_extent(const GasDesc &gd, int j, int ncol, int nlay) {
   return (size_t)(1 + (long long)(ncol - 1) * cs + (long long)(nlay - 1) * ls);
 }
 
+// Planck side of a longwave call, for the fused kernel.
+struct PlanckSide {
+  const double *tlev, *tsfc;
+  double *lay_source, *lev_inc, *lev_dec, *sfc_source;
+};
+
 // gas_optical_depth (src/gas_optics_ecckd.f90:323-376) on device pointers.  `sw` selects the
-// gas_optics_ext epilogue (:455-460).
+// gas_optics_ext epilogue (:455-460).  When `pl` is given and the fast arithmetic mode is on, the
+// Planck sources (:407-424) are produced by the same launch and *planck_done is set.
 int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double *plev,
                           const double *tlay, const GasDesc &gd, double *tau, bool sw, double *ssa,
-                          double *g, hipStream_t stream) {
+                          double *g, const PlanckSide *pl, bool *planck_done, hipStream_t stream) {
   using namespace ecckd;
+  if (planck_done) *planck_done = false;
   std::vector<SeqGas> seq;
   bool first_calc = true;   // :347
   for (int j = 0; j < gd.ngas; ++j) {   // :348
@@ -140,12 +152,15 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     if (t.composite_only) first_calc = false;   // :371-373
   }
 
-  // Split the sequence into passes holding at most one look_up_table gas each; later passes
-  // start from the tau already stored, so the summation order of :370 is preserved exactly.
+  // Split the sequence into passes holding at most one look_up_table gas and kTauPassGases
+  // gases each; later passes start from the tau already stored, so the summation order of :370
+  // is preserved exactly in the reference-order mode.
+  const bool fast = g_arith == 0;
   size_t pos = 0;
   bool first_pass = true;
   do {
-    TauArgs a{};
+    FusedArgs fa{};
+    TauArgs &a = fa.tau;
     a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.np = m->np; a.nt = m->nt;
     a.plev = plev; a.tlay = tlay;
     a.temperature = m->dbuf + m->off_temperature;
@@ -159,6 +174,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     a.nseq = 0;
     while (pos < seq.size()) {
       SeqGas e = seq[pos];
+      if (a.nseq >= kTauPassGases) break;
       if (e.code == ECCKD_LOOK_UP_TABLE) {
         if (a.lut >= 0) break;
         a.lut = a.nseq;
@@ -177,7 +193,25 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
       a.ssa = ssa;
       a.g = g;
     }
-    {
+    if (fast) {
+      fa.mode = (sw && last) ? 2 : 0;
+      const int nv_lut = a.lut >= 0 ? a.seq[a.lut].nv : 0;
+      // Planck sources ride along with the first pass when the table fits next to >= 3 slab rows
+      if (pl && first_pass && !sw &&
+          fused_slab_rows(a.ng, a.np, a.nt, a.nbil, nv_lut, m->ntp, 3) > 0) {
+        fa.mode = 1;
+        fa.ntp = m->ntp;
+        fa.planck = m->dbuf + m->off_planck;
+        fa.pt0 = m->temperature_planck[0];                                  // :272
+        fa.pdt = m->temperature_planck[1] - m->temperature_planck[0];      // :271
+        fa.tlev = pl->tlev; fa.tsfc = pl->tsfc;
+        fa.lay_source = pl->lay_source; fa.lev_source_inc = pl->lev_inc;
+        fa.lev_source_dec = pl->lev_dec; fa.sfc_source = pl->sfc_source;
+        if (planck_done) *planck_done = true;
+      }
+      ProfScope prof(fa.mode == 1 ? "gas_lw_fused" : "tau", stream);
+      HIPCHK(launch_gas_fused(fa, stream));
+    } else {
       ProfScope prof("tau", stream);
       HIPCHK(launch_tau(a, stream));
     }
@@ -257,6 +291,14 @@ const char *ecckd_build_info(void) {
 }
 
 // ------------------------------- kernel timing hooks -------------------------------------
+
+int ecckd_set_arithmetic(int mode) {
+  if (mode != 0 && mode != 1) return fail("ecckd_set_arithmetic: mode must be 0 (fast) or 1 (reference order)");
+  g_arith = mode;
+  return 0;
+}
+
+int ecckd_get_arithmetic(void) { return g_arith; }
 
 int ecckd_prof_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof_mu);
@@ -490,7 +532,11 @@ static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const dou
                              const double *tlay, const double *tsfc, const double *tlev,
                              const GasDesc &gd, double *tau, double *lay_source, double *lev_inc,
                              double *lev_dec, double *sfc_source, hipStream_t stream) {
-  if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, false, nullptr, nullptr, stream)) return 1;   // :401
+  const PlanckSide pl{tlev, tsfc, lay_source, lev_inc, lev_dec, sfc_source};
+  bool planck_done = false;
+  if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, false, nullptr, nullptr, &pl, &planck_done, stream))
+    return 1;   // :401
+  if (planck_done) return 0;
   ecckd::PlanckArgs p{};
   p.ncol = ncol; p.nlay = nlay; p.ng = m->ng; p.ntp = m->ntp;
   p.planck = m->dbuf + m->off_planck;
@@ -565,7 +611,7 @@ static int gas_optics_sw_dev(const ecckd_model *m, int ncol, int nlay, const dou
                              double *g, double *toa_src, hipStream_t stream) {
   const bool two_stream = ssa && g;
   if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, true, two_stream ? ssa : nullptr,
-                            two_stream ? g : nullptr, stream))   // :449-460
+                            two_stream ? g : nullptr, nullptr, nullptr, stream))   // :449-460
     return 1;
   if (!two_stream) return 0;   // caller reports :461-463 after tau has been written
   HIPCHK(ecckd::launch_toa_src(m->dbuf + m->off_solar, ncol, m->ng, toa_src, stream));   // :468-472

@@ -7,6 +7,7 @@
 namespace ecckd {
 
 constexpr int kMaxSeq = 16;          // src/gas_optics_ecckd.f90:24 (at most 16 tables)
+constexpr int kTauPassGases = 10;    // gases one tau launch accumulates (more -> another pass)
 constexpr int kLdsBudget = 160 * 1024;
 
 // One entry of the per-call gas sequence: a table of the model matched to a gas of gas_desc,
@@ -46,6 +47,17 @@ struct TauArgs {
   int col_chunks;              // grid.x; each block walks tiles chunk by chunk
 };
 
+// Fused gas-optics launch (kernels_gas_fused.hip): the tau arguments plus the Planck side.
+struct FusedArgs {
+  TauArgs tau;
+  int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
+  int ntp;
+  const double *planck;        // (ng,ntp) device
+  double pt0, pdt;             // temperature_planck(1), (2)-(1)
+  const double *tlev, *tsfc;   // tlev may be nullptr
+  double *lay_source, *lev_source_inc, *lev_source_dec, *sfc_source;
+};
+
 struct PlanckArgs {
   int ncol, nlay, ng, ntp;
   const double *planck;        // (ng,ntp) device
@@ -83,6 +95,8 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows);
+hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);

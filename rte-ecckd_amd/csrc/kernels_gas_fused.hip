@@ -1,0 +1,513 @@
+// kernels_gas_fused.hip -- gas optics in one pass: optical depth of all gases AND (longwave) the
+// three Planck source arrays, or (shortwave) the Rayleigh/ssa/g epilogue.
+//
+// Replaces, for one call of gas_optics_int / gas_optics_ext (src/gas_optics_ecckd.f90:381-473):
+// calculate_optical_depth x ngas + the tau accumulation (:64-241, :348-374),
+// calculate_planck_function x 3 (:245-289, :407-424) or the Rayleigh epilogue (:293-319, :455-460).
+//
+// Why one kernel: on gfx950 the interpolation is bound by LDS read issue (36 coefficient reads
+// per cell) and fp64 VALU, the Planck sources by HBM stores (24 B/cell).  Run back to back they
+// take the sum; fused, the arithmetic hides under the stores and the pass is HBM-bound
+// (32 B/cell written: tau, lay_source, lev_source_inc, lev_source_dec).
+//
+// Arithmetic ("fast" mode, the default): the four (eight) interpolation weights of a cell are
+// multiplied out once per (column,layer) and every coefficient costs one FMA,
+//     od_gas(g) = w_gas * (a00*c00 + a10*c10 + a01*c01 + a11*c11),   a_pt = tw_t * pw_p,
+// the look_up_table gas is summed first and the other gases in gas_desc order.  That is the
+// reference's formula re-associated: tau agrees with the reference-order kernels
+// (kernels_tau.hip, kept as the bit-faithful mode) to a few ulp; the stated test tolerance is
+// 1e-12 relative.  Per-gas clamping of negative optical depths (:234-238) is kept exactly:
+// tables without negative entries (all ecCKD files) clamp the weight instead, tables with
+// negative entries take the ANYCLAMP instantiation.  Planck sources are computed in the
+// reference's order and are bit-identical.
+//
+// Mapping: lane -> column, block = kBlock columns of ONE layer (grid.y), LDS = slab of R pressure
+// rows of every active table (+ the whole Planck table), rows padded to an odd length; see
+// kernels_tau.hip for the slab logic, which is the same.
+#include "kernels.hpp"
+
+namespace ecckd {
+namespace {
+
+#ifndef ECCKD_FUSED_BLOCK
+#define ECCKD_FUSED_BLOCK 512
+#endif
+#ifndef ECCKD_FUSED_SPAN
+#define ECCKD_FUSED_SPAN 4
+#endif
+constexpr int kBlock = ECCKD_FUSED_BLOCK;
+constexpr int kWaves = kBlock / 64;
+constexpr int kSeg = 8;    // tiles between two slab-range checks (block barriers)
+constexpr int kSpan = ECCKD_FUSED_SPAN;
+
+__device__ __forceinline__ double selmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double selmax(double a, double b) { return a > b ? a : b; }
+
+struct FLayout {
+  int tb, red, bil, SB, lut, SL, pl, SP, total;
+};
+
+// NB = bilinear slots the kernel reads per row (>= nbil; the row holds nbil*ng values and the
+// slab is followed by a pad so that the zero-weight slots read finite data).
+__host__ __device__ inline FLayout f_layout(int ng, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp) {
+  FLayout L;
+  L.tb = 0;
+  L.red = (np + 1) & ~1;
+  L.bil = L.red + kWaves;
+  L.SB = nbil > 0 ? ((nbil * ng) | 1) : 1;
+  L.lut = L.bil + R * nt * L.SB + NB * ng;
+  L.SL = nv_lut > 0 ? (ng | 1) : 1;
+  L.pl = L.lut + (nv_lut > 0 ? R * nt * nv_lut * L.SL : 0) + ng;
+  L.SP = ng | 1;
+  L.total = L.pl + (ntp > 0 ? ntp * L.SP : 0);
+  return L;
+}
+
+struct PPoint { int ip0; double pw0, pw1; };
+__device__ __forceinline__ PPoint pressure_point(double p0, double p1, double lp0, double dlp, int np) {
+  const double log_pressure = log(0.5 * (p1 + p0));                      // :120
+  double pressure_index = (log_pressure - lp0) / dlp;
+  pressure_index = 1. + selmax(0., selmin(pressure_index, (double)np - 1.0001));
+  PPoint r;
+  r.ip0 = (int)pressure_index;
+  r.pw1 = pressure_index - r.ip0;
+  r.pw0 = 1. - r.pw1;
+  return r;
+}
+
+// Planck interpolation point (:275-285).  Below the table the reference uses (T/t0)*B(:,1); that
+// is row 0 with weights (T/t0, 0): w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.
+struct PlPoint { int off; double w0, w1; };
+__device__ __forceinline__ PlPoint planck_point(double T, double t0, double dt, int ntp, int SP) {
+  PlPoint p;
+  double temperature_index = (T - t0) / dt;
+  if (temperature_index >= 0) {
+    temperature_index = 1. + temperature_index;
+    const int it0 = temperature_index >= (double)(ntp - 1) ? ntp - 1 : (int)temperature_index;
+    p.w1 = temperature_index - it0;
+    p.w0 = 1. - p.w1;
+    p.off = (it0 - 1) * SP;
+  } else {
+    p.w0 = T / t0;
+    p.w1 = 0.;
+    p.off = 0;
+  }
+  return p;
+}
+
+__device__ __forceinline__ double div_pi(double x, double pi, double rpi) {
+  const double q = x * rpi;              // correctly rounded x/pi (Markstein), see kernels_planck.hip
+  const double r = fma(-q, pi, x);
+  return fma(r, rpi, q);
+}
+
+enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
+
+template <int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+__global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
+  extern __shared__ double lds[];
+  typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+  lds_cvd *lv = (lds_cvd *)lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.y;
+  const TauArgs &t = a.tau;
+  const int ncol = t.ncol, nlay = t.nlay, ng = t.ng, np = t.np, nt = t.nt, R = t.R;
+  const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
+  const int ntp = MODE == MODE_LW ? a.ntp : 0;
+  const FLayout L = f_layout(ng, np, nt, t.nbil, NB, nv_lut, R, ntp);
+  int *red = reinterpret_cast<int *>(lds + L.red);
+
+  // Everything a zero-weight slot (unused bilinear slot, absent look_up_table gas) can read must
+  // be finite: clear the whole allocation once, the staged rows overwrite their part.
+  for (int i = tid; i < L.total; i += kBlock) lds[i] = 0.;
+  __syncthreads();
+  for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = t.temperature[i];
+  if (MODE == MODE_LW) {
+    for (int q = tid; q < ntp * ng; q += kBlock) {
+      const int r = q / ng, g = q - r * ng;
+      lds[L.pl + r * L.SP + g] = a.planck[q];
+    }
+  }
+
+  const long ntiles = ((long)ncol + kBlock - 1) / kBlock;
+  const long t_begin = ntiles * blockIdx.x / gridDim.x;
+  const long t_end = ntiles * (blockIdx.x + 1) / gridDim.x;
+  int slab_lo = -1;
+  const double *plev0 = t.plev + (long)ncol * j, *plev1 = t.plev + (long)ncol * (j + 1);
+  const double pi = (double)3.14159265359f, rpi = 1. / pi;   // :53
+
+  for (long seg = t_begin; seg < t_end; seg += kSeg) {
+    const long seg_end = seg + kSeg < t_end ? seg + kSeg : t_end;
+    // ---- pre-pass: pressure-row range of the segment ----
+    int vmin = np, vmax = 0;
+    for (long tile = seg; tile < seg_end; ++tile) {
+      const long c = tile * kBlock + tid;
+      if (c < ncol) {
+        const int ip0 = pressure_point(plev0[c], plev1[c], t.lp0, t.dlp, np).ip0;
+        vmin = min(vmin, ip0);
+        vmax = max(vmax, ip0);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = min(vmin, __shfl_xor(vmin, o));
+      vmax = max(vmax, __shfl_xor(vmax, o));
+    }
+    __syncthreads();
+    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+    __syncthreads();
+    int ipmin = red[0], ipmax = red[1];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) { ipmin = min(ipmin, red[2 * w]); ipmax = max(ipmax, red[2 * w + 1]); }
+    if (R >= 2 && ipmin <= ipmax && !(slab_lo >= 0 && ipmin - 1 >= slab_lo && ipmax <= slab_lo + R - 1)) {
+      slab_lo = min(ipmin - 1, np - R);
+      const int rows_b = R * nt;
+      const int items_b = rows_b * t.nbil;
+      for (int q = wave; q < items_b; q += kWaves) {
+        const int s = q % t.nbil, rb = q / t.nbil;
+        const int ipl = rb % R, it = rb / R;
+        const double *src = t.seq[t.bil_seq[s]].coef + (long)ng * ((slab_lo + ipl) + (long)np * it);
+        double *dst = lds + L.bil + rb * L.SB + s * ng;
+        for (int g = lane; g < ng; g += 64) dst[g] = src[g];
+      }
+      if (t.lut >= 0) {
+        const double *coef = t.seq[t.lut].coef;
+        const int rows_l = rows_b * nv_lut;
+        for (int q = wave; q < rows_l; q += kWaves) {
+          const int ipl = q % R, itv = q / R;
+          const double *src = coef + (long)ng * ((slab_lo + ipl) + (long)np * itv);
+          double *dst = lds + L.lut + q * L.SL;
+          for (int g = lane; g < ng; g += 64) dst[g] = src[g];
+        }
+      }
+    }
+    __syncthreads();
+
+    for (long tile = seg; tile < seg_end; ++tile) {
+      const long c = tile * kBlock + tid;
+      const bool valid = c < ncol;
+      const long cc = valid ? c : (long)ncol - 1;
+      // ---- setup: one round of global loads ----
+      const double p0 = plev0[cc], p1 = plev1[cc];
+      const double T = t.tlay[cc + (long)ncol * j];
+      double W[NB];        // per-slot weight (:143-149), 0 for unused slots
+      double vlut = 0.;    // vmr of the look_up_table gas
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        W[s] = 0.;
+        if (s < t.nbil) {
+          const SeqGas &e = t.seq[t.bil_seq[s]];
+          W[s] = e.vmr ? e.vmr[cc * e.cs + j * e.ls] : e.scalar;
+        }
+      }
+      if (t.lut >= 0) {
+        const SeqGas &e = t.seq[t.lut];
+        vlut = e.vmr ? e.vmr[cc * e.cs + j * e.ls] : e.scalar;
+      }
+      double Tl0 = 0., Tl1 = 0.;
+      if (MODE == MODE_LW && a.tlev) {
+        Tl0 = a.tlev[cc + (long)ncol * j];
+        Tl1 = a.tlev[cc + (long)ncol * (j + 1)];
+      }
+
+      const PPoint pp = pressure_point(p0, p1, t.lp0, t.dlp, np);
+      const int ip0 = pp.ip0;
+      const int ipl = ip0 - 1 - slab_lo;
+      const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
+      const bool fast = __all(inslab);
+
+      const double t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
+      double temperature_index = (T - t0) / t.dt;
+      temperature_index = 1. + selmax(0., selmin(temperature_index, (double)nt - 1.0001));
+      const int it0 = (int)temperature_index;
+      const double tw1 = temperature_index - it0;
+      const double tw0 = 1. - tw1;
+      const double dp = p1 - p0;
+      const double simple_weight = t.gw * dp;   // :143
+
+      // corner weights, multiplied out once per cell
+      const double a00 = tw0 * pp.pw0, a10 = tw0 * pp.pw1, a01 = tw1 * pp.pw0, a11 = tw1 * pp.pw1;
+      double l000 = 0., l100 = 0., l010 = 0., l110 = 0., l001 = 0., l101 = 0., l011 = 0., l111 = 0.;
+      int iv0 = 1;
+      if (t.lut >= 0) {   // :153-163
+        const SeqGas &e = t.seq[t.lut];
+        const double log_vmr = log(selmax(vlut, e.mf0));
+        double vmr_index = (log_vmr - e.log_mf0) / e.d_log_vmr;
+        vmr_index = 1. + selmax(0., selmin(vmr_index, (double)e.nv - 1.001));
+        iv0 = (int)vmr_index;
+        const double vw1 = vmr_index - iv0, vw0 = 1. - vw1;
+        double wl = simple_weight * vlut;   // :148
+        if (!ANYCLAMP) wl = wl < 0. ? 0. : wl;
+        const double u0 = ANYCLAMP ? vw0 : wl * vw0, u1 = ANYCLAMP ? vw1 : wl * vw1;
+        l000 = u0 * a00; l100 = u0 * a10; l010 = u0 * a01; l110 = u0 * a11;
+        l001 = u1 * a00; l101 = u1 * a10; l011 = u1 * a01; l111 = u1 * a11;
+        if (ANYCLAMP) vlut = wl;   // keep the weight; applied (and clamped) per g-point
+      }
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        if (s < t.nbil) {
+          const SeqGas &e = t.seq[t.bil_seq[s]];
+          double x = e.code == 3 ? simple_weight * (W[s] - e.ref)
+                                 : (e.code == 0 ? simple_weight : simple_weight * W[s]);
+          if (!ANYCLAMP) x = x < 0. ? 0. : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
+          W[s] = x;
+        }
+      }
+
+      PlPoint qlay{0, 0., 0.}, ql0{0, 0., 0.}, ql1{0, 0., 0.};
+      if (MODE == MODE_LW) {
+        qlay = planck_point(T, a.pt0, a.pdt, ntp, L.SP);
+        ql0 = planck_point(Tl0, a.pt0, a.pdt, ntp, L.SP);
+        ql1 = planck_point(Tl1, a.pt0, a.pdt, ntp, L.SP);
+      }
+      const double moles = dp * t.gw;   // :313-314 (SW)
+
+      if (fast) {
+        // The g-point work of a chunk is a static sequence of "items" -- one g-point of the
+        // look_up_table gas (8 reads), BG g-points of one bilinear slot (4*BG reads), PG g-points
+        // of the Planck sources (6*PG reads) -- software-pipelined by hand: the LDS reads of item
+        // i+1 are issued before the arithmetic of item i.  Reads are volatile (kept in program
+        // order, never paired into ds_read2_b64) and every item ends in an empty asm that pins
+        // its results, otherwise instruction selection floats all arithmetic below all reads.
+        constexpr int BG = (GC % 4 == 0) ? 4 : (GC % 3 == 0 ? 3 : 1);
+        constexpr int PG = (GC % 2 == 0) ? 2 : 1;
+        constexpr int NLI = GC, NBI = NB * (GC / BG), NPI = (MODE == MODE_LW) ? GC / PG : 0;
+        constexpr int NIT = NLI + NBI + NPI;
+        int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
+        int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
+        const int dPb = L.SB, dTb = R * L.SB;
+        const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
+        for (int gb = 0; gb < ng; gb += GC, ob += GC, ol += GC) {
+          double acc[GC];
+          if (t.accumulate) {
+#pragma unroll
+            for (int g = 0; g < GC; ++g)
+              acc[g] = (FULL || gb + g < ng) ? t.tau[cc + (long)ncol * (j + (long)nlay * (gb + g))] : 0.;
+          } else {
+#pragma unroll
+            for (int g = 0; g < GC; ++g) acc[g] = 0.;
+          }
+          const int pb = L.pl + gb;
+          double buf[2][16];
+#pragma unroll
+          for (int it = 0; it <= NIT; ++it) {
+            // ---------------- issue the reads of item `it` ----------------
+            if (it < NLI) {
+              const int g = it;
+              double *b = buf[it & 1];
+              b[0] = lv[ol + g];             b[1] = lv[ol + dPl + g];
+              b[2] = lv[ol + dTl + g];       b[3] = lv[ol + dTl + dPl + g];
+              b[4] = lv[ol + dVl + g];       b[5] = lv[ol + dVl + dPl + g];
+              b[6] = lv[ol + dVl + dTl + g]; b[7] = lv[ol + dVl + dTl + dPl + g];
+            } else if (it < NLI + NBI) {
+              const int s = (it - NLI) / (GC / BG), g0 = ((it - NLI) % (GC / BG)) * BG;
+              double *b = buf[it & 1];
+#pragma unroll
+              for (int q = 0; q < BG; ++q) {
+                const int o = ob + s * ng + g0 + q;
+                b[4 * q + 0] = lv[o];       b[4 * q + 1] = lv[o + dPb];
+                b[4 * q + 2] = lv[o + dTb]; b[4 * q + 3] = lv[o + dTb + dPb];
+              }
+            } else if (it < NIT) {
+              const int g0 = (it - NLI - NBI) * PG;
+              double *b = buf[it & 1];
+#pragma unroll
+              for (int q = 0; q < PG; ++q) {
+                const int g = g0 + q;
+                b[6 * q + 0] = lv[pb + qlay.off + g]; b[6 * q + 1] = lv[pb + qlay.off + L.SP + g];
+                b[6 * q + 2] = lv[pb + ql0.off + g];  b[6 * q + 3] = lv[pb + ql0.off + L.SP + g];
+                b[6 * q + 4] = lv[pb + ql1.off + g];  b[6 * q + 5] = lv[pb + ql1.off + L.SP + g];
+              }
+            }
+            // ---------------- arithmetic of item `it - 1` ----------------
+            if (it >= 1) {
+              const int pi_ = it - 1;
+              const double *b = buf[pi_ & 1];
+              if (pi_ < NLI) {
+                const int g = pi_;
+                double v = l000 * b[0];
+                v = fma(l100, b[1], v); v = fma(l010, b[2], v); v = fma(l110, b[3], v);
+                v = fma(l001, b[4], v); v = fma(l101, b[5], v); v = fma(l011, b[6], v);
+                v = fma(l111, b[7], v);
+                if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
+                acc[g] = acc[g] + v;
+                asm volatile("" : "+v"(acc[g]));
+              } else if (pi_ < NLI + NBI) {
+                const int s = (pi_ - NLI) / (GC / BG), g0 = ((pi_ - NLI) % (GC / BG)) * BG;
+#pragma unroll
+                for (int q = 0; q < BG; ++q) {
+                  double v = a00 * b[4 * q];
+                  v = fma(a10, b[4 * q + 1], v); v = fma(a01, b[4 * q + 2], v); v = fma(a11, b[4 * q + 3], v);
+                  if (ANYCLAMP) { v = W[s] * v; v = v < 0. ? 0. : v; acc[g0 + q] = acc[g0 + q] + v; }
+                  else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
+                  asm volatile("" : "+v"(acc[g0 + q]));
+                }
+                if (pi_ == NLI + NBI - 1 && valid) {   // tau of this chunk is complete
+#pragma unroll
+                  for (int g = 0; g < GC; ++g) {
+                    if (FULL || gb + g < ng) {
+                      const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
+                      if (MODE == MODE_SW) {
+                        const double ray = moles * t.rayleigh[gb + g];   // :316
+                        const double tt = acc[g] + ray;                   // :456
+                        t.tau[o] = tt;
+                        if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }  // :459-460
+                      } else {
+                        t.tau[o] = acc[g];
+                      }
+                    }
+                  }
+                }
+              } else {
+                const int g0 = (pi_ - NLI - NBI) * PG;
+#pragma unroll
+                for (int q = 0; q < PG; ++q) {
+                  const int g = g0 + q;
+                  if (FULL || gb + g < ng) {
+                    const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
+                    const double vl = div_pi(qlay.w0 * b[6 * q] + qlay.w1 * b[6 * q + 1], pi, rpi);
+                    const double v0 = div_pi(ql0.w0 * b[6 * q + 2] + ql0.w1 * b[6 * q + 3], pi, rpi);
+                    const double v1 = div_pi(ql1.w0 * b[6 * q + 4] + ql1.w1 * b[6 * q + 5], pi, rpi);
+                    if (valid) {
+                      a.lay_source[o] = vl;
+                      if (a.tlev) { a.lev_source_dec[o] = v0; a.lev_source_inc[o] = v1; }   // :423-424
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+      } else {
+        // ---- a lane of this wave is outside the staged rows: tables from global memory ----
+        for (int g = 0; g < ng; ++g) {
+          const long o = cc + (long)ncol * (j + (long)nlay * g);
+          double acc = t.accumulate ? t.tau[o] : 0.;
+          if (t.lut >= 0) {
+            const SeqGas &e = t.seq[t.lut];
+            const double *cp = e.coef + (long)ng * ((ip0 - 1) + (long)np * ((it0 - 1) + (long)nt * (iv0 - 1))) + g;
+            const long dP = ng, dT = (long)ng * np, dV = (long)ng * np * nt;
+            double v = l000 * cp[0];
+            v = fma(l100, cp[dP], v);
+            v = fma(l010, cp[dT], v);
+            v = fma(l110, cp[dT + dP], v);
+            v = fma(l001, cp[dV], v);
+            v = fma(l101, cp[dV + dP], v);
+            v = fma(l011, cp[dV + dT], v);
+            v = fma(l111, cp[dV + dT + dP], v);
+            if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
+            acc = acc + v;
+          }
+#pragma unroll
+          for (int s = 0; s < NB; ++s) {
+            if (s < t.nbil) {
+              const double *cp = t.seq[t.bil_seq[s]].coef + (long)ng * ((ip0 - 1) + (long)np * (it0 - 1)) + g;
+              const long dP = ng, dT = (long)ng * np;
+              double v = a00 * cp[0];
+              v = fma(a10, cp[dP], v);
+              v = fma(a01, cp[dT], v);
+              v = fma(a11, cp[dT + dP], v);
+              if (ANYCLAMP) { v = W[s] * v; v = v < 0. ? 0. : v; acc = acc + v; }
+              else acc = fma(W[s], v, acc);
+            }
+          }
+          if (valid) {
+            if (MODE == MODE_SW) {
+              const double ray = moles * t.rayleigh[g];
+              const double tt = acc + ray;
+              t.tau[o] = tt;
+              if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }
+            } else {
+              t.tau[o] = acc;
+            }
+            if (MODE == MODE_LW) {
+              const int pb = L.pl + g;
+              a.lay_source[o] = div_pi(qlay.w0 * lv[pb + qlay.off] + qlay.w1 * lv[pb + qlay.off + L.SP], pi, rpi);
+              if (a.tlev) {
+                a.lev_source_dec[o] = div_pi(ql0.w0 * lv[pb + ql0.off] + ql0.w1 * lv[pb + ql0.off + L.SP], pi, rpi);
+                a.lev_source_inc[o] = div_pi(ql1.w0 * lv[pb + ql1.off] + ql1.w1 * lv[pb + ql1.off + L.SP], pi, rpi);
+              }
+            }
+          }
+        }
+      }
+
+      // ---- surface source (:408-413), by the blocks of the first layer ----
+      if (MODE == MODE_LW && j == 0 && valid) {
+        const PlPoint qs = planck_point(a.tsfc[c], a.pt0, a.pdt, ntp, L.SP);
+        for (int g = 0; g < ng; ++g)
+          a.sfc_source[c + (long)ncol * g] =
+              div_pi(qs.w0 * lv[L.pl + qs.off + g] + qs.w1 * lv[L.pl + qs.off + L.SP + g], pi, rpi);
+      }
+    }
+  }
+}
+
+template <int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
+  auto k = gas_fused_kernel<GC, NB, FULL, ANYCLAMP, MODE>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(a.tau.col_chunks, a.tau.nlay), dim3(kBlock), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp, hipStream_t s) {
+  const int ng = a.tau.ng;
+  if (!anyclamp) {
+    if (NBsel == 7 && ng % 8 == 0) return launch_one<8, 7, true, false, MODE>(a, lds, s);
+    if (NBsel == 7 && ng % 9 == 0) return launch_one<9, 7, true, false, MODE>(a, lds, s);
+    if (NBsel == 5 && ng % 9 == 0) return launch_one<9, 5, true, false, MODE>(a, lds, s);
+    return launch_one<8, kTauPassGases, false, false, MODE>(a, lds, s);
+  }
+  return launch_one<8, kTauPassGases, false, true, MODE>(a, lds, s);
+}
+
+int pick_nb(int nbil, int ng) {
+  if (nbil <= 5 && ng % 9 == 0) return 5;
+  if (nbil <= 7 && (ng % 8 == 0 || ng % 9 == 0)) return 7;
+  return kTauPassGases;
+}
+
+}  // namespace
+
+// Rows of the LDS slab for a fused launch, or 0 if it does not fit with at least `min_rows`.
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows) {
+  const int NB = pick_nb(nbil, ng);
+  int R = 0;
+  for (int r = 2; r <= np; ++r) {
+    if (sizeof(double) * (size_t)f_layout(ng, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
+    else break;
+  }
+  return R >= min_rows ? R : 0;
+}
+
+hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
+  TauArgs &t = a.tau;
+  if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;
+  if (t.nseq > kTauPassGases) return hipErrorInvalidValue;
+  const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
+  const int ntp = a.mode == MODE_LW ? a.ntp : 0;
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0);
+  const int NB = pick_nb(t.nbil, t.ng);
+  const size_t lds = sizeof(double) * (size_t)f_layout(t.ng, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
+  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+  bool anyclamp = false;
+  for (int k = 0; k < t.nseq; ++k) anyclamp |= t.seq[k].clamp != 0;
+  // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
+  // round of blocks full
+  const long ntiles = ((long)t.ncol + kBlock - 1) / kBlock;
+  long chunks = 1;
+  while ((chunks * t.nlay) % 256 != 0 && chunks < 256) ++chunks;
+  while (chunks * 2 * kSeg <= ntiles && chunks * t.nlay < 2048) chunks *= 2;
+  if (chunks * kSeg > ntiles) chunks = (ntiles + kSeg - 1) / kSeg;
+  if (chunks < 1) chunks = 1;
+  t.col_chunks = (int)chunks;
+  if (a.mode == MODE_LW) return launch_mode<MODE_LW>(a, lds, NB, anyclamp, s);
+  if (a.mode == MODE_SW) return launch_mode<MODE_SW>(a, lds, NB, anyclamp, s);
+  return launch_mode<MODE_TAU>(a, lds, NB, anyclamp, s);
+}
+
+}  // namespace ecckd

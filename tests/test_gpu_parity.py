@@ -17,6 +17,15 @@ TAU_RTOL = 1e-12
 FLUX_ATOL = 1e-9
 
 
+@pytest.fixture(autouse=True, params=["fast", "reference_order"])
+def arithmetic(request, pkg):
+    """Every test runs in both arithmetic modes of the library (ecckd_set_arithmetic): the fused
+    fast kernel (default) and the reference-expression-order kernels."""
+    pkg.set_arithmetic(pkg.FAST if request.param == "fast" else pkg.REFERENCE_ORDER)
+    yield request.param
+    pkg.set_arithmetic(pkg.FAST)
+
+
 @pytest.fixture(scope="module")
 def lw(pkg, gpu, oracle_mod):
     k = pkg.GasOpticsEcckd()
@@ -274,6 +283,19 @@ def test_sw_gas_optics_and_rte_sw(pkg, gpu, oracle_mod):
     op.tau, op.ssa, op.g = t(f(otau)), t(f(ossa)), t(f(og))
     assert pkg.rte_sw(op, False, t(cols["mu0"]), toa, t(alb_dir), t(alb_dif), fl) == ""
     assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)) < FLUX_ATOL
+
+
+def test_modes_agree_to_a_few_ulp(pkg, gpu, lw):
+    """fast vs reference-order arithmetic: same formula, re-associated."""
+    k, _ = lw
+    cols = edge_columns(k.get_press_min(), 256)
+    pkg.set_arithmetic(pkg.REFERENCE_ORDER)
+    r = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    pkg.set_arithmetic(pkg.FAST)
+    f = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    assert helpers.max_rel(f[1], r[1]) < 5e-15
+    for a, b in zip(f[2:], r[2:]):
+        assert np.array_equal(a, b)          # Planck sources: identical in both modes
 
 
 def test_golden_fixture_on_gpu(pkg, gpu, lw):
