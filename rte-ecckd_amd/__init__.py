@@ -56,6 +56,41 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+FORTRAN_DIR = os.path.join(_HERE, "fortran")
+FORTRAN_DRIVER = os.path.join(FORTRAN_DIR, "build", "ecckd_driver")
+_FORTRAN_SOURCES = ["mo_rte_min.F90", "gas_optics_ecckd.F90", "mo_rte_solvers.F90", "ecckd_driver.F90"]
+
+
+def build_fortran(force=False, verbose=False):
+    """Compile the Fortran drop-in module, the solver shims and the host driver with amdflang and
+    link them against librte_ecckd_hip.so.  Returns the driver path, or None if no Fortran compiler
+    is installed (the C ABI and the Python mirror do not need one)."""
+    fc = os.environ.get("FC", "/opt/rocm/bin/amdflang")
+    if not os.path.exists(fc):
+        return None
+    srcs = [os.path.join(FORTRAN_DIR, s) for s in _FORTRAN_SOURCES]
+    bdir = os.path.dirname(FORTRAN_DRIVER)
+    if not force and os.path.exists(FORTRAN_DRIVER):
+        t = os.path.getmtime(FORTRAN_DRIVER)
+        if all(os.path.getmtime(d) <= t for d in srcs + [LIB_PATH]):
+            return FORTRAN_DRIVER
+    os.makedirs(bdir, exist_ok=True)
+    objs = []
+    for s in srcs:
+        o = os.path.join(bdir, os.path.basename(s)[:-4] + ".o")
+        cmd = [fc, "-O2", "-module-dir", bdir, "-I" + bdir, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [fc, "-o", FORTRAN_DRIVER] + objs + ["-L" + _HERE, "-lrte_ecckd_hip", "-Wl,-rpath,$ORIGIN/../..",
+                                               "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FORTRAN_DRIVER
+
+
 _lib = None
 _dp = C.POINTER(C.c_double)
 

@@ -1,0 +1,134 @@
+! ecckd_driver.F90 -- Fortran host program over the drop-in module, shaped like the block loop of
+! example/rfmip-rad-irf/ecckd_rfmip_lw.F90:107-136 and ecckd_rfmip_sw.F90:112-162: load the ecCKD
+! file, then per column block gas_optics() followed by rte_lw()/rte_sw(), fluxes out.
+!
+!   ecckd_driver lw|sw  <ecckd_file.nc>  <input.bin>  <output.bin>  [block_size] [n_quad_angles]
+!
+! input.bin (little-endian, written by tests/test_fortran_shim.py): int32 ncol, nlay, ngas; per gas
+! a 32-char name; then float64 arrays in Fortran order: plev(ncol,nlay+1), tlev(ncol,nlay+1),
+! tlay(ncol,nlay), tsfc(ncol), sfc_emis(ncol) [lw] or mu0(ncol), albedo(ncol) [sw], then per gas
+! vmr(ncol,nlay).  output.bin: flux_up(ncol,nlay+1), flux_dn(ncol,nlay+1).
+! (The RFMIP netCDF files the reference drivers read are an FTP download and not available here.)
+program ecckd_driver
+  use, intrinsic :: iso_fortran_env, only: error_unit, int32
+  use gas_optics_ecckd, only: ty_gas_optics_ecckd
+  use mo_fluxes, only: ty_fluxes_broadband
+  use mo_gas_concentrations, only: ty_gas_concs
+  use mo_optical_props, only: ty_optical_props_1scl, ty_optical_props_2str
+  use mo_rte_kind, only: wp
+  use mo_rte_lw, only: rte_lw
+  use mo_rte_sw, only: rte_sw
+  use mo_source_functions, only: ty_source_func_lw
+  implicit none
+  character(len=512) :: mode, ecckd_path, in_path, out_path, arg
+  integer(int32) :: ncol, nlay, ngas
+  integer :: block_size, n_quad_angles, nblocks, b, c0, c1, nc, i, ibnd, nbnd, u
+  logical :: top_at_1, lw
+  character(len=32), dimension(:), allocatable :: gas_names
+  real(wp), dimension(:,:), allocatable :: plev, tlev, tlay, play
+  real(wp), dimension(:), allocatable :: tsfc, bc1, bc2
+  real(wp), dimension(:,:,:), allocatable :: vmr
+  real(wp), dimension(:,:), allocatable, target :: flux_up, flux_dn
+  real(wp), dimension(:,:), allocatable :: sfc_spec, sfc_spec2, toa
+  type(ty_gas_optics_ecckd) :: ecckd
+  type(ty_gas_concs) :: gas_concs
+  type(ty_source_func_lw) :: source
+  type(ty_optical_props_1scl) :: op1
+  type(ty_optical_props_2str) :: op2
+  type(ty_fluxes_broadband) :: fluxes
+
+  if (command_argument_count() < 4) then
+    write(error_unit, *) "usage: ecckd_driver lw|sw ecckd_file input.bin output.bin [block_size] [n_quad_angles]"
+    stop 1
+  end if
+  call get_command_argument(1, mode)
+  call get_command_argument(2, ecckd_path)
+  call get_command_argument(3, in_path)
+  call get_command_argument(4, out_path)
+  block_size = 0
+  n_quad_angles = 1
+  if (command_argument_count() >= 5) then
+    call get_command_argument(5, arg)
+    read(arg, *) block_size
+  end if
+  if (command_argument_count() >= 6) then
+    call get_command_argument(6, arg)
+    read(arg, *) n_quad_angles
+  end if
+  lw = trim(mode) == "lw"
+
+  open(newunit=u, file=trim(in_path), access="stream", form="unformatted", status="old")
+  read(u) ncol, nlay, ngas
+  allocate(gas_names(ngas))
+  read(u) gas_names
+  allocate(plev(ncol, nlay + 1), tlev(ncol, nlay + 1), tlay(ncol, nlay), play(ncol, nlay), tsfc(ncol), &
+           bc1(ncol), bc2(ncol), vmr(ncol, nlay, ngas))
+  read(u) plev, tlev, tlay, tsfc
+  if (lw) then
+    read(u) bc1
+  else
+    read(u) bc1, bc2
+  end if
+  read(u) vmr
+  close(u)
+  play = 0.5_wp * (plev(:, 1:nlay) + plev(:, 2:nlay + 1))
+  if (block_size <= 0) block_size = ncol
+
+  call stop_on_err(ecckd%load(trim(ecckd_path)))
+  if (lw .neqv. ecckd%source_is_internal()) call stop_on_err("ecckd_driver: k-distribution file doesn't match lw/sw")
+  nbnd = ecckd%get_nband()
+  top_at_1 = play(1, 1) < play(1, nlay)                   ! ecckd_rfmip_lw.F90:85
+  allocate(flux_up(ncol, nlay + 1), flux_dn(ncol, nlay + 1))
+  nblocks = (ncol + block_size - 1) / block_size
+
+  do b = 1, nblocks
+    c0 = (b - 1) * block_size + 1
+    c1 = min(ncol, b * block_size)
+    nc = c1 - c0 + 1
+    call stop_on_err(gas_concs%init(gas_names))
+    do i = 1, ngas
+      call stop_on_err(gas_concs%set_vmr(trim(gas_names(i)), vmr(c0:c1, :, i)))
+    end do
+    fluxes%flux_up => flux_up(c0:c1, :)
+    fluxes%flux_dn => flux_dn(c0:c1, :)
+    if (allocated(sfc_spec)) deallocate(sfc_spec)
+    allocate(sfc_spec(nbnd, nc))
+    do i = 1, nc                                             ! ecckd_rfmip_lw.F90:112-116
+      do ibnd = 1, nbnd
+        sfc_spec(ibnd, i) = bc1(c0 + i - 1)
+      end do
+    end do
+    if (lw) then
+      call stop_on_err(source%alloc(nc, nlay, ecckd))
+      call stop_on_err(op1%alloc_1scl(nc, nlay, ecckd))
+      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), tsfc(c0:c1), gas_concs, &
+                                        op1, source, tlev=tlev(c0:c1, :)))
+      call stop_on_err(rte_lw(op1, top_at_1, source, sfc_spec, fluxes, n_gauss_angles=n_quad_angles))
+    else
+      if (allocated(sfc_spec2)) deallocate(sfc_spec2, toa)
+      allocate(sfc_spec2(nbnd, nc), toa(nc, ecckd%get_ngpt()))
+      do i = 1, nc
+        sfc_spec(:, i) = bc2(c0 + i - 1)                     ! albedo, direct = diffuse (ecckd_rfmip_sw.F90:136-141)
+        sfc_spec2(:, i) = bc2(c0 + i - 1)
+      end do
+      call stop_on_err(op2%alloc_2str(nc, nlay, ecckd))
+      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), gas_concs, op2, toa))
+      call stop_on_err(rte_sw(op2, top_at_1, bc1(c0:c1), toa, sfc_spec, sfc_spec2, fluxes))
+    end if
+  end do
+
+  open(newunit=u, file=trim(out_path), access="stream", form="unformatted", status="replace")
+  write(u) flux_up, flux_dn
+  close(u)
+  call ecckd%finalize()
+  write(error_unit, *) "ecckd_driver: ", ncol, " columns in ", nblocks, " blocks done"
+
+contains
+  subroutine stop_on_err(msg)                                ! mo_simple_netcdf.F90:331-339
+    character(len=*), intent(in) :: msg
+    if (len_trim(msg) > 0) then
+      write(error_unit, *) trim(msg)
+      stop 1
+    end if
+  end subroutine stop_on_err
+end program ecckd_driver

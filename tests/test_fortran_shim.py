@@ -1,0 +1,99 @@
+"""The reference-language host side: the Fortran drop-in module `gas_optics_ecckd` (iso_c_binding
+shim over the C ABI) driven by a Fortran program shaped like ecckd_rfmip_lw/sw.F90, built with
+amdflang by __graft_entry__.build(), run here as a child process and checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from conftest import LW_FSCK, SW_WIDE
+from rte_ecckd_amd import synthetic
+
+FLUX_ATOL = 1e-9
+
+
+def write_input(path, cols, names, shortwave):
+    nlay, ncol = cols["tlay"].shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", ncol, nlay, len(names)))
+        for n in names:
+            f.write(n.encode().ljust(32, b" "))
+        f64 = lambda a: f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+        f64(cols["plev"]); f64(cols["tlev"]); f64(cols["tlay"]); f64(cols["tsfc"])
+        if shortwave:
+            f64(cols["mu0"]); f64(cols["albedo"])
+        else:
+            f64(cols["sfc_emis"])
+        for n in names:
+            v = cols[n]
+            full = np.broadcast_to(np.asarray(v, dtype=np.float64) if not np.isscalar(v) else np.float64(v), (nlay, ncol))
+            f64(full)
+
+
+def read_output(path, ncol, nlay):
+    a = np.fromfile(path, dtype="<f8")
+    assert a.size == 2 * ncol * (nlay + 1)
+    return a[:ncol * (nlay + 1)].reshape(nlay + 1, ncol), a[ncol * (nlay + 1):].reshape(nlay + 1, ncol)
+
+
+def test_fortran_sources_compile(pkg):
+    """CPU: the shim and driver build with amdflang against the C ABI library (skipped without it)."""
+    drv = pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no amdflang in this image")
+    assert os.path.exists(drv)
+    out = subprocess.run([drv], capture_output=True, text=True)
+    assert out.returncode != 0 and "usage: ecckd_driver" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,nquad", [(0, 1), (7, 1), (64, 3)])
+def test_fortran_lw_driver(pkg, gpu, oracle_mod, tmp_path, block, nquad):
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    m = oracle_mod.CkdModel(LW_FSCK)
+    ncol = 100                                                   # "100 column test cases", README.md:25
+    cols = synthetic.columns(0, ncol, float(np.exp(m.log_pressure[0])))
+    names = synthetic.GAS_ORDER
+    write_input(tmp_path / "in.bin", cols, names, False)
+    r = subprocess.run([drv, "lw", LW_FSCK, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(block), str(nquad)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fu, fd = read_output(tmp_path / "out.bin", ncol, 60)
+    tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                           helpers.oracle_gas_items(cols, names), cols["tlev"])
+    ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], 32, 0), sfc, nmus=nquad)
+    assert np.max(np.abs(fu - ofu)) < FLUX_ATOL and np.max(np.abs(fd - ofd)) < FLUX_ATOL
+
+
+@pytest.mark.gpu
+def test_fortran_sw_driver(pkg, gpu, oracle_mod, tmp_path):
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    m = oracle_mod.CkdModel(SW_WIDE)
+    ncol = 100
+    cols = synthetic.columns(0, ncol, float(np.exp(m.log_pressure[0])), shortwave=True)
+    names = synthetic.GAS_ORDER
+    write_input(tmp_path / "in.bin", cols, names, True)
+    r = subprocess.run([drv, "sw", SW_WIDE, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "32"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fu, fd = read_output(tmp_path / "out.bin", ncol, 60)
+    tau, ssa, g, toa, _ = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, names))
+    alb = np.repeat(cols["albedo"][None], 27, 0)
+    ofu, ofd, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb)
+    assert np.max(np.abs(fu - ofu)) < FLUX_ATOL and np.max(np.abs(fd - ofd)) < FLUX_ATOL
+
+
+@pytest.mark.gpu
+def test_fortran_error_path(pkg, gpu, tmp_path):
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    r = subprocess.run([drv, "lw", str(tmp_path / "missing.nc"), "x", "y"], capture_output=True, text=True)
+    assert r.returncode != 0            # stop_on_err -> stop 1 (mo_simple_netcdf.F90:331-339)
