@@ -45,11 +45,16 @@ struct TauArgs {
   // launch geometry chosen by the host
   int R;                       // pressure rows of the LDS slab
   int col_chunks;              // grid.x; each block walks tiles chunk by chunk
+  int debug_nostore;           // ECCKD_DEBUG_NOSTORE=1: skip the output stores (timing experiments only)
 };
+
+// Division by a wave-uniform constant, d with its reciprocal (kernels_gas_fused.hip: udiv()).
+struct UDiv { double d, r; int exact; };
 
 // Fused gas-optics launch (kernels_gas_fused.hip): the tau arguments plus the Planck side.
 struct FusedArgs {
   TauArgs tau;
+  UDiv ud_dlp, ud_dt, ud_dlv, ud_pdt;   // filled by launch_gas_fused
   int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
   int ntp;
   const double *planck;        // (ng,ntp) device
@@ -95,7 +100,7 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);

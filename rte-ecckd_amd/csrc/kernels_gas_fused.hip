@@ -24,6 +24,8 @@
 // Mapping: lane -> column, block = kBlock columns of ONE layer (grid.y), LDS = slab of R pressure
 // rows of every active table (+ the whole Planck table), rows padded to an odd length; see
 // kernels_tau.hip for the slab logic, which is the same.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -47,26 +49,43 @@ struct FLayout {
   int tb, red, bil, SB, lut, SL, pl, SP, total;
 };
 
-// NB = bilinear slots the kernel reads per row (>= nbil; the row holds nbil*ng values and the
-// slab is followed by a pad so that the zero-weight slots read finite data).
-__host__ __device__ inline FLayout f_layout(int ng, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp) {
+// Row strides are == 2 (mod 4) doubles: every row starts 16-byte aligned (ds_read_b128 of two
+// consecutive g-points) and consecutive rows are shifted by 4 banks, so the 16 lanes of a b128
+// lane group that sit in different rows do not collide.
+__host__ __device__ inline int row_stride(int n) { return n + ((6 - (n & 3)) & 3); }
+
+// NB  = bilinear slots the kernel reads per row (>= nbil; the slab is followed by a pad so that the
+//       zero-weight slots read finite data).
+// ngp = g-points per row in LDS: ng rounded up to the chunk size GC (the tail stays zero).
+__host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp) {
   FLayout L;
   L.tb = 0;
   L.red = (np + 1) & ~1;
-  L.bil = L.red + kWaves;
-  L.SB = nbil > 0 ? ((nbil * ng) | 1) : 1;
-  L.lut = L.bil + R * nt * L.SB + NB * ng;
-  L.SL = nv_lut > 0 ? (ng | 1) : 1;
-  L.pl = L.lut + (nv_lut > 0 ? R * nt * nv_lut * L.SL : 0) + ng;
-  L.SP = ng | 1;
+  L.bil = L.red + 2 * kWaves;
+  L.SB = nbil > 0 ? row_stride(nbil * ngp) : 2;
+  L.lut = L.bil + R * nt * L.SB + NB * ngp;
+  L.SL = nv_lut > 0 ? row_stride(ngp) : 2;
+  L.pl = L.lut + (nv_lut > 0 ? R * nt * nv_lut * L.SL : 0) + ngp;
+  L.SP = row_stride(ngp);
   L.total = L.pl + (ntp > 0 ? ntp * L.SP : 0);
   return L;
 }
 
+// x / d for a wave-uniform divisor d with r = 1/d precomputed (correctly rounded): Markstein's
+// correction step returns the correctly rounded quotient, i.e. exactly what `x / d` returns, in
+// 3 instructions instead of the ~30 of the IEEE division sequence.  (Precondition checked on the
+// host: d finite, non-zero, significand not all ones; otherwise exact is 0 and `/` is used.)
+__device__ __forceinline__ double udiv(double x, const UDiv &u) {
+  if (!u.exact) return x / u.d;
+  const double q = x * u.r;
+  const double rem = fma(-q, u.d, x);
+  return fma(rem, u.r, q);
+}
+
 struct PPoint { int ip0; double pw0, pw1; };
-__device__ __forceinline__ PPoint pressure_point(double p0, double p1, double lp0, double dlp, int np) {
+__device__ __forceinline__ PPoint pressure_point(double p0, double p1, double lp0, const UDiv &dlp, int np) {
   const double log_pressure = log(0.5 * (p1 + p0));                      // :120
-  double pressure_index = (log_pressure - lp0) / dlp;
+  double pressure_index = udiv(log_pressure - lp0, dlp);
   pressure_index = 1. + selmax(0., selmin(pressure_index, (double)np - 1.0001));
   PPoint r;
   r.ip0 = (int)pressure_index;
@@ -78,9 +97,9 @@ __device__ __forceinline__ PPoint pressure_point(double p0, double p1, double lp
 // Planck interpolation point (:275-285).  Below the table the reference uses (T/t0)*B(:,1); that
 // is row 0 with weights (T/t0, 0): w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.
 struct PlPoint { int off; double w0, w1; };
-__device__ __forceinline__ PlPoint planck_point(double T, double t0, double dt, int ntp, int SP) {
+__device__ __forceinline__ PlPoint planck_point(double T, double t0, const UDiv &dt, int ntp, int SP) {
   PlPoint p;
-  double temperature_index = (T - t0) / dt;
+  double temperature_index = udiv(T - t0, dt);
   if (temperature_index >= 0) {
     temperature_index = 1. + temperature_index;
     const int it0 = temperature_index >= (double)(ntp - 1) ? ntp - 1 : (int)temperature_index;
@@ -103,19 +122,59 @@ __device__ __forceinline__ double div_pi(double x, double pi, double rpi) {
 
 enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
 
+// Value of the neighbouring lane (lane ^ 1): two DPP moves, no LDS traffic.
+__device__ __forceinline__ double swap_adjacent(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Stores the values of two consecutive g-points (planes o0, o1 of a column-fastest array) as ONE
+// 16-byte store per lane instead of two 8-byte ones: the lanes of an (even, odd) column pair
+// exchange one value, then the even lane writes both columns of plane 0 and the odd lane both
+// columns of plane 1.  Per CU the store path moves ~7 B/clk with dwordx2 and about twice that with
+// dwordx4 (the kernel was store-issue bound).  Must be called by all lanes of the wave.
+//   c: column of this lane (even lanes hold even columns); o0, o1: element offsets of (column 0,
+//   plane) ; ok: this lane's column exists; pair_ok: both columns of the pair exist.
+__device__ __forceinline__ void store_pair(double *arr, long c, long o0, long o1, double v0, double v1,
+                                           bool odd, bool ok, bool pair_ok) {
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  const double recv = swap_adjacent(odd ? v0 : v1);
+  if (pair_ok) {
+    double2_t out;
+    out[0] = odd ? recv : v0;
+    out[1] = odd ? v1 : recv;
+    const long ce = c - (odd ? 1 : 0);
+#ifdef ECCKD_NT_STORES
+    __builtin_nontemporal_store(out, reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce));
+#else
+    *reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce) = out;
+#endif
+  } else if (ok) {   // last column of an odd ncol
+    arr[o0 + c] = v0;
+    arr[o1 + c] = v1;
+  }
+}
+
 template <int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
 __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  typedef double double2_t __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+  typedef __attribute__((address_space(3))) const volatile double2_t lds_cvd2;
   lds_cvd *lv = (lds_cvd *)lds;
+  // two consecutive g-points in one ds_read_b128 (x must be even)
+  auto ld2 = [&](int x) -> double2_t { return *(lds_cvd2 *)(lv + x); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = blockIdx.y;
   const TauArgs &t = a.tau;
   const int ncol = t.ncol, nlay = t.nlay, ng = t.ng, np = t.np, nt = t.nt, R = t.R;
   const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
   const int ntp = MODE == MODE_LW ? a.ntp : 0;
-  const FLayout L = f_layout(ng, np, nt, t.nbil, NB, nv_lut, R, ntp);
-  int *red = reinterpret_cast<int *>(lds + L.red);
+  const int ngp = (ng + GC - 1) / GC * GC;
+  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, ntp);
+  double *redd = lds + L.red;
 
   // Everything a zero-weight slot (unused bilinear slot, absent look_up_table gas) can read must
   // be finite: clear the whole allocation once, the staged rows overwrite their part.
@@ -138,27 +197,33 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
   for (long seg = t_begin; seg < t_end; seg += kSeg) {
     const long seg_end = seg + kSeg < t_end ? seg + kSeg : t_end;
-    // ---- pre-pass: pressure-row range of the segment ----
-    int vmin = np, vmax = 0;
+    // ---- pre-pass: range of p0+p1 over the segment; the pressure index is monotone in it ----
+    double smin = 1.0e300, smax = -1.0e300;
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
       if (c < ncol) {
-        const int ip0 = pressure_point(plev0[c], plev1[c], t.lp0, t.dlp, np).ip0;
-        vmin = min(vmin, ip0);
-        vmax = max(vmax, ip0);
+        const double sp = plev1[c] + plev0[c];
+        smin = selmin(smin, sp);
+        smax = selmax(smax, sp);
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      vmin = min(vmin, __shfl_xor(vmin, o));
-      vmax = max(vmax, __shfl_xor(vmax, o));
+      smin = selmin(smin, __shfl_xor(smin, o));
+      smax = selmax(smax, __shfl_xor(smax, o));
     }
+    __syncthreads();   // the previous segment's LDS reads are done
+    if (lane == 0) { redd[2 * wave] = smin; redd[2 * wave + 1] = smax; }
     __syncthreads();
-    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
-    __syncthreads();
-    int ipmin = red[0], ipmax = red[1];
+    smin = redd[0]; smax = redd[1];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) { ipmin = min(ipmin, red[2 * w]); ipmax = max(ipmax, red[2 * w + 1]); }
+    for (int w = 1; w < kWaves; ++w) { smin = selmin(smin, redd[2 * w]); smax = selmax(smax, redd[2 * w + 1]); }
+    int ipmin = 1, ipmax = 0;
+    if (smin <= smax) {
+      // same expression as pressure_point(): log(0.5*(p1+p0)); 0 + s == s exactly
+      ipmin = pressure_point(0., smin, t.lp0, a.ud_dlp, np).ip0;
+      ipmax = pressure_point(0., smax, t.lp0, a.ud_dlp, np).ip0;
+    }
     if (R >= 2 && ipmin <= ipmax && !(slab_lo >= 0 && ipmin - 1 >= slab_lo && ipmax <= slab_lo + R - 1)) {
       slab_lo = min(ipmin - 1, np - R);
       const int rows_b = R * nt;
@@ -167,7 +232,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         const int s = q % t.nbil, rb = q / t.nbil;
         const int ipl = rb % R, it = rb / R;
         const double *src = t.seq[t.bil_seq[s]].coef + (long)ng * ((slab_lo + ipl) + (long)np * it);
-        double *dst = lds + L.bil + rb * L.SB + s * ng;
+        double *dst = lds + L.bil + rb * L.SB + s * ngp;
         for (int g = lane; g < ng; g += 64) dst[g] = src[g];
       }
       if (t.lut >= 0) {
@@ -185,8 +250,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
-      const bool valid = c < ncol;
-      const long cc = valid ? c : (long)ncol - 1;
+      const bool valid = c < ncol && !t.debug_nostore;
+      const bool odd = (tid & 1) != 0;
+      const bool pair_ok = ((c | 1) < ncol) && !t.debug_nostore;   // both columns of this lane pair exist
+      const long cc = c < ncol ? c : (long)ncol - 1;
       // ---- setup: one round of global loads ----
       const double p0 = plev0[cc], p1 = plev1[cc];
       const double T = t.tlay[cc + (long)ncol * j];
@@ -210,14 +277,14 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         Tl1 = a.tlev[cc + (long)ncol * (j + 1)];
       }
 
-      const PPoint pp = pressure_point(p0, p1, t.lp0, t.dlp, np);
+      const PPoint pp = pressure_point(p0, p1, t.lp0, a.ud_dlp, np);
       const int ip0 = pp.ip0;
       const int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
       const bool fast = __all(inslab);
 
       const double t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
-      double temperature_index = (T - t0) / t.dt;
+      double temperature_index = udiv(T - t0, a.ud_dt);
       temperature_index = 1. + selmax(0., selmin(temperature_index, (double)nt - 1.0001));
       const int it0 = (int)temperature_index;
       const double tw1 = temperature_index - it0;
@@ -232,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       if (t.lut >= 0) {   // :153-163
         const SeqGas &e = t.seq[t.lut];
         const double log_vmr = log(selmax(vlut, e.mf0));
-        double vmr_index = (log_vmr - e.log_mf0) / e.d_log_vmr;
+        double vmr_index = udiv(log_vmr - e.log_mf0, a.ud_dlv);
         vmr_index = 1. + selmax(0., selmin(vmr_index, (double)e.nv - 1.001));
         iv0 = (int)vmr_index;
         const double vw1 = vmr_index - iv0, vw0 = 1. - vw1;
@@ -256,9 +323,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       PlPoint qlay{0, 0., 0.}, ql0{0, 0., 0.}, ql1{0, 0., 0.};
       if (MODE == MODE_LW) {
-        qlay = planck_point(T, a.pt0, a.pdt, ntp, L.SP);
-        ql0 = planck_point(Tl0, a.pt0, a.pdt, ntp, L.SP);
-        ql1 = planck_point(Tl1, a.pt0, a.pdt, ntp, L.SP);
+        qlay = planck_point(T, a.pt0, a.ud_pdt, ntp, L.SP);
+        ql0 = planck_point(Tl0, a.pt0, a.ud_pdt, ntp, L.SP);
+        ql1 = planck_point(Tl1, a.pt0, a.ud_pdt, ntp, L.SP);
       }
       const double moles = dp * t.gw;   // :313-314 (SW)
 
@@ -269,15 +336,14 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         // i+1 are issued before the arithmetic of item i.  Reads are volatile (kept in program
         // order, never paired into ds_read2_b64) and every item ends in an empty asm that pins
         // its results, otherwise instruction selection floats all arithmetic below all reads.
-        constexpr int BG = (GC % 4 == 0) ? 4 : (GC % 3 == 0 ? 3 : 1);
-        constexpr int PG = (GC % 2 == 0) ? 2 : 1;
-        constexpr int NLI = GC, NBI = NB * (GC / BG), NPI = (MODE == MODE_LW) ? GC / PG : 0;
+        static_assert(GC % 4 == 0, "chunks are made of g-point pairs and quads");
+        constexpr int NLI = GC / 2, NBI = NB * (GC / 4), NPI = (MODE == MODE_LW) ? GC / 2 : 0;
         constexpr int NIT = NLI + NBI + NPI;
         int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
         int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
         const int dPb = L.SB, dTb = R * L.SB;
         const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
-        for (int gb = 0; gb < ng; gb += GC, ob += GC, ol += GC) {
+        for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
           double acc[GC];
           if (t.accumulate) {
 #pragma unroll
@@ -288,70 +354,80 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
             for (int g = 0; g < GC; ++g) acc[g] = 0.;
           }
           const int pb = L.pl + gb;
-          double buf[2][16];
+          double2_t buf[2][8];
 #pragma unroll
           for (int it = 0; it <= NIT; ++it) {
             // ---------------- issue the reads of item `it` ----------------
-            if (it < NLI) {
-              const int g = it;
-              double *b = buf[it & 1];
-              b[0] = lv[ol + g];             b[1] = lv[ol + dPl + g];
-              b[2] = lv[ol + dTl + g];       b[3] = lv[ol + dTl + dPl + g];
-              b[4] = lv[ol + dVl + g];       b[5] = lv[ol + dVl + dPl + g];
-              b[6] = lv[ol + dVl + dTl + g]; b[7] = lv[ol + dVl + dTl + dPl + g];
-            } else if (it < NLI + NBI) {
-              const int s = (it - NLI) / (GC / BG), g0 = ((it - NLI) % (GC / BG)) * BG;
-              double *b = buf[it & 1];
-#pragma unroll
-              for (int q = 0; q < BG; ++q) {
-                const int o = ob + s * ng + g0 + q;
-                b[4 * q + 0] = lv[o];       b[4 * q + 1] = lv[o + dPb];
-                b[4 * q + 2] = lv[o + dTb]; b[4 * q + 3] = lv[o + dTb + dPb];
-              }
-            } else if (it < NIT) {
-              const int g0 = (it - NLI - NBI) * PG;
-              double *b = buf[it & 1];
-#pragma unroll
-              for (int q = 0; q < PG; ++q) {
-                const int g = g0 + q;
-                b[6 * q + 0] = lv[pb + qlay.off + g]; b[6 * q + 1] = lv[pb + qlay.off + L.SP + g];
-                b[6 * q + 2] = lv[pb + ql0.off + g];  b[6 * q + 3] = lv[pb + ql0.off + L.SP + g];
-                b[6 * q + 4] = lv[pb + ql1.off + g];  b[6 * q + 5] = lv[pb + ql1.off + L.SP + g];
-              }
+            if (it < NLI) {                       // look_up_table gas, g-points 2*it, 2*it+1
+              const int g = 2 * it;
+              double2_t *b = buf[it & 1];
+              b[0] = ld2(ol + g);             b[1] = ld2(ol + dPl + g);
+              b[2] = ld2(ol + dTl + g);       b[3] = ld2(ol + dTl + dPl + g);
+              b[4] = ld2(ol + dVl + g);       b[5] = ld2(ol + dVl + dPl + g);
+              b[6] = ld2(ol + dVl + dTl + g); b[7] = ld2(ol + dVl + dTl + dPl + g);
+            } else if (it < NLI + NBI) {          // one bilinear slot, 4 g-points
+              const int s = (it - NLI) / (GC / 4), g0 = ((it - NLI) % (GC / 4)) * 4;
+              double2_t *b = buf[it & 1];
+              const int o = ob + s * ngp + g0;
+              b[0] = ld2(o);       b[1] = ld2(o + dPb);       b[2] = ld2(o + dTb);     b[3] = ld2(o + dTb + dPb);
+              b[4] = ld2(o + 2);   b[5] = ld2(o + dPb + 2);   b[6] = ld2(o + dTb + 2); b[7] = ld2(o + dTb + dPb + 2);
+            } else if (it < NIT) {                // Planck sources, 2 g-points
+              const int g = 2 * (it - NLI - NBI);
+              double2_t *b = buf[it & 1];
+              b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
+              b[2] = ld2(pb + ql0.off + g);  b[3] = ld2(pb + ql0.off + L.SP + g);
+              b[4] = ld2(pb + ql1.off + g);  b[5] = ld2(pb + ql1.off + L.SP + g);
             }
             // ---------------- arithmetic of item `it - 1` ----------------
             if (it >= 1) {
               const int pi_ = it - 1;
-              const double *b = buf[pi_ & 1];
+              const double2_t *b = buf[pi_ & 1];
               if (pi_ < NLI) {
-                const int g = pi_;
-                double v = l000 * b[0];
-                v = fma(l100, b[1], v); v = fma(l010, b[2], v); v = fma(l110, b[3], v);
-                v = fma(l001, b[4], v); v = fma(l101, b[5], v); v = fma(l011, b[6], v);
-                v = fma(l111, b[7], v);
-                if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
-                acc[g] = acc[g] + v;
-                asm volatile("" : "+v"(acc[g]));
-              } else if (pi_ < NLI + NBI) {
-                const int s = (pi_ - NLI) / (GC / BG), g0 = ((pi_ - NLI) % (GC / BG)) * BG;
 #pragma unroll
-                for (int q = 0; q < BG; ++q) {
-                  double v = a00 * b[4 * q];
-                  v = fma(a10, b[4 * q + 1], v); v = fma(a01, b[4 * q + 2], v); v = fma(a11, b[4 * q + 3], v);
+                for (int q = 0; q < 2; ++q) {
+                  const int g = 2 * pi_ + q;
+                  double v = l000 * b[0][q];
+                  v = fma(l100, b[1][q], v); v = fma(l010, b[2][q], v); v = fma(l110, b[3][q], v);
+                  v = fma(l001, b[4][q], v); v = fma(l101, b[5][q], v); v = fma(l011, b[6][q], v);
+                  v = fma(l111, b[7][q], v);
+                  if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
+                  acc[g] = acc[g] + v;
+                  asm volatile("" : "+v"(acc[g]));
+                }
+              } else if (pi_ < NLI + NBI) {
+                const int s = (pi_ - NLI) / (GC / 4), g0 = ((pi_ - NLI) % (GC / 4)) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int h = (q >> 1) * 4, e = q & 1;
+                  double v = a00 * b[h][e];
+                  v = fma(a10, b[h + 1][e], v); v = fma(a01, b[h + 2][e], v); v = fma(a11, b[h + 3][e], v);
                   if (ANYCLAMP) { v = W[s] * v; v = v < 0. ? 0. : v; acc[g0 + q] = acc[g0 + q] + v; }
                   else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
                   asm volatile("" : "+v"(acc[g0 + q]));
                 }
-                if (pi_ == NLI + NBI - 1 && valid) {   // tau of this chunk is complete
+                if (pi_ == NLI + NBI - 1) {   // tau of this chunk is complete
 #pragma unroll
-                  for (int g = 0; g < GC; ++g) {
-                    if (FULL || gb + g < ng) {
+                  for (int g = 0; g < GC; g += 2) {
+                    if (FULL || gb + g + 1 < ng) {
+                      const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
+                      if (MODE == MODE_SW) {
+                        const double r0 = moles * t.rayleigh[gb + g], r1 = moles * t.rayleigh[gb + g + 1];   // :316
+                        const double t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
+                        store_pair(t.tau, c, o0, o1, t0_, t1_, odd, valid, pair_ok);
+                        if (t.ssa) {                                                                          // :459-460
+                          store_pair(t.ssa, c, o0, o1, r0 / t0_, r1 / t1_, odd, valid, pair_ok);
+                          store_pair(t.g, c, o0, o1, 0., 0., odd, valid, pair_ok);
+                        }
+                      } else {
+                        store_pair(t.tau, c, o0, o1, acc[g], acc[g + 1], odd, valid, pair_ok);
+                      }
+                    } else if (gb + g < ng && valid) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
                       if (MODE == MODE_SW) {
-                        const double ray = moles * t.rayleigh[gb + g];   // :316
-                        const double tt = acc[g] + ray;                   // :456
+                        const double ray = moles * t.rayleigh[gb + g];
+                        const double tt = acc[g] + ray;
                         t.tau[o] = tt;
-                        if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }  // :459-460
+                        if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }
                       } else {
                         t.tau[o] = acc[g];
                       }
@@ -359,20 +435,25 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   }
                 }
               } else {
-                const int g0 = (pi_ - NLI - NBI) * PG;
+                const int g = 2 * (pi_ - NLI - NBI);
+                double vl[2], v0[2], v1[2];
 #pragma unroll
-                for (int q = 0; q < PG; ++q) {
-                  const int g = g0 + q;
-                  if (FULL || gb + g < ng) {
-                    const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
-                    const double vl = div_pi(qlay.w0 * b[6 * q] + qlay.w1 * b[6 * q + 1], pi, rpi);
-                    const double v0 = div_pi(ql0.w0 * b[6 * q + 2] + ql0.w1 * b[6 * q + 3], pi, rpi);
-                    const double v1 = div_pi(ql1.w0 * b[6 * q + 4] + ql1.w1 * b[6 * q + 5], pi, rpi);
-                    if (valid) {
-                      a.lay_source[o] = vl;
-                      if (a.tlev) { a.lev_source_dec[o] = v0; a.lev_source_inc[o] = v1; }   // :423-424
-                    }
+                for (int q = 0; q < 2; ++q) {
+                  vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
+                  v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
+                  v1[q] = div_pi(ql1.w0 * b[4][q] + ql1.w1 * b[5][q], pi, rpi);
+                }
+                if (FULL || gb + g + 1 < ng) {
+                  const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
+                  store_pair(a.lay_source, c, o0, o1, vl[0], vl[1], odd, valid, pair_ok);
+                  if (a.tlev) {                                                      // :423-424
+                    store_pair(a.lev_source_dec, c, o0, o1, v0[0], v0[1], odd, valid, pair_ok);
+                    store_pair(a.lev_source_inc, c, o0, o1, v1[0], v1[1], odd, valid, pair_ok);
                   }
+                } else if (gb + g < ng && valid) {
+                  const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
+                  a.lay_source[o] = vl[0];
+                  if (a.tlev) { a.lev_source_dec[o] = v0[0]; a.lev_source_inc[o] = v1[0]; }
                 }
               }
             }
@@ -434,7 +515,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       // ---- surface source (:408-413), by the blocks of the first layer ----
       if (MODE == MODE_LW && j == 0 && valid) {
-        const PlPoint qs = planck_point(a.tsfc[c], a.pt0, a.pdt, ntp, L.SP);
+        const PlPoint qs = planck_point(a.tsfc[c], a.pt0, a.ud_pdt, ntp, L.SP);
         for (int g = 0; g < ng; ++g)
           a.sfc_source[c + (long)ncol * g] =
               div_pi(qs.w0 * lv[L.pl + qs.off + g] + qs.w1 * lv[L.pl + qs.off + L.SP + g], pi, rpi);
@@ -453,49 +534,84 @@ hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Chunk size: 8 g-points when ng is a multiple of 8, else 4 (rows are padded to a multiple of it).
+int pick_gc(int ng) { return ng % 8 == 0 ? 8 : 4; }
+
+int pick_nb(int nbil) {
+  if (nbil <= 5) return 5;
+  if (nbil <= 7) return 7;
+  return kTauPassGases;
+}
+
 template <int MODE>
 hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp, hipStream_t s) {
   const int ng = a.tau.ng;
-  if (!anyclamp) {
-    if (NBsel == 7 && ng % 8 == 0) return launch_one<8, 7, true, false, MODE>(a, lds, s);
-    if (NBsel == 7 && ng % 9 == 0) return launch_one<9, 7, true, false, MODE>(a, lds, s);
-    if (NBsel == 5 && ng % 9 == 0) return launch_one<9, 5, true, false, MODE>(a, lds, s);
-    return launch_one<8, kTauPassGases, false, false, MODE>(a, lds, s);
-  }
-  return launch_one<8, kTauPassGases, false, true, MODE>(a, lds, s);
+  if (anyclamp) return launch_one<4, kTauPassGases, false, true, MODE>(a, lds, s);
+  if (NBsel == 7 && ng % 8 == 0) return launch_one<8, 7, true, false, MODE>(a, lds, s);
+  if (NBsel == 7 && ng % 4 == 0) return launch_one<4, 7, true, false, MODE>(a, lds, s);
+  if (NBsel == 5) return launch_one<4, 5, false, false, MODE>(a, lds, s);
+  return launch_one<4, kTauPassGases, false, false, MODE>(a, lds, s);
 }
 
-int pick_nb(int nbil, int ng) {
-  if (nbil <= 5 && ng % 9 == 0) return 5;
-  if (nbil <= 7 && (ng % 8 == 0 || ng % 9 == 0)) return 7;
-  return kTauPassGases;
+// (GC, NB) of the instantiation launch_mode() will pick
+void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
+  const int nb = pick_nb(nbil);
+  if (anyclamp) { *GC = 4; *NB = kTauPassGases; }
+  else if (nb == 7 && ng % 8 == 0) { *GC = 8; *NB = 7; }
+  else if (nb == 7 && ng % 4 == 0) { *GC = 4; *NB = 7; }
+  else if (nb == 5) { *GC = 4; *NB = 5; }
+  else { *GC = 4; *NB = kTauPassGases; }
 }
 
 }  // namespace
 
 // Rows of the LDS slab for a fused launch, or 0 if it does not fit with at least `min_rows`.
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows) {
-  const int NB = pick_nb(nbil, ng);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp) {
+  int GC, NB;
+  pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
+  const int ngp = (ng + GC - 1) / GC * GC;
   int R = 0;
   for (int r = 2; r <= np; ++r) {
-    if (sizeof(double) * (size_t)f_layout(ng, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
+    if (sizeof(double) * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
     else break;
   }
   return R >= min_rows ? R : 0;
 }
 
+UDiv make_udiv(double d) {
+  UDiv u;
+  u.d = d;
+  u.r = 1. / d;
+  unsigned long long bits;
+  static_assert(sizeof(bits) == sizeof(d), "");
+  __builtin_memcpy(&bits, &d, 8);
+  const bool all_ones = (bits & 0xFFFFFFFFFFFFFULL) == 0xFFFFFFFFFFFFFULL;
+  u.exact = (d == d) && d != 0. && (d - d == 0.) && !all_ones && (u.r - u.r == 0.) ? 1 : 0;
+  return u;
+}
+
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   TauArgs &t = a.tau;
+  a.ud_dlp = make_udiv(t.dlp);
+  a.ud_dt = make_udiv(t.dt);
+  a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1.);
+  a.ud_pdt = make_udiv(a.mode == MODE_LW ? a.pdt : 1.);
   if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;
   if (t.nseq > kTauPassGases) return hipErrorInvalidValue;
+  {
+    const char *e = getenv("ECCKD_DEBUG_NOSTORE");
+    t.debug_nostore = (e && e[0] == '1') ? 1 : 0;
+  }
   const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
   const int ntp = a.mode == MODE_LW ? a.ntp : 0;
-  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0);
-  const int NB = pick_nb(t.nbil, t.ng);
-  const size_t lds = sizeof(double) * (size_t)f_layout(t.ng, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
-  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   bool anyclamp = false;
   for (int k = 0; k < t.nseq; ++k) anyclamp |= t.seq[k].clamp != 0;
+  int GC, NB;
+  pick_shape(t.ng, t.nbil, anyclamp, &GC, &NB);
+  const int ngp = (t.ng + GC - 1) / GC * GC;
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0, anyclamp);
+  const size_t lds = sizeof(double) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
+  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full
   const long ntiles = ((long)t.ncol + kBlock - 1) / kBlock;
@@ -505,9 +621,9 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   if (chunks * kSeg > ntiles) chunks = (ntiles + kSeg - 1) / kSeg;
   if (chunks < 1) chunks = 1;
   t.col_chunks = (int)chunks;
-  if (a.mode == MODE_LW) return launch_mode<MODE_LW>(a, lds, NB, anyclamp, s);
-  if (a.mode == MODE_SW) return launch_mode<MODE_SW>(a, lds, NB, anyclamp, s);
-  return launch_mode<MODE_TAU>(a, lds, NB, anyclamp, s);
+  if (a.mode == MODE_LW) return launch_mode<MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  if (a.mode == MODE_SW) return launch_mode<MODE_SW>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  return launch_mode<MODE_TAU>(a, lds, pick_nb(t.nbil), anyclamp, s);
 }
 
 }  // namespace ecckd

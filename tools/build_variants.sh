@@ -1,22 +1,23 @@
 #!/bin/bash
 # Builds experimental variants of the library next to the product .so so that one gpurun call can
-# A/B them (tools/ab.py):   tools/build_variants.sh "<flags for kernels_tau.hip>" ...
-# Each argument is a set of extra hipcc flags; a leading "ALL:" applies them to every source.
+# A/B them (tools/ab.py):   tools/build_variants.sh "<extra hipcc flags>" ...
+# Flags apply to the gas-optics kernels (kernels_gas_fused.hip, kernels_tau.hip); a leading "ALL:"
+# applies them to every source.
 set -e
 cd "$(dirname "$0")/../rte-ecckd_amd/csrc"
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off"
 mkdir -p ../../variants_tmp /tmp/ecckd_var
 i=0
 for v in "$@"; do
   i=$((i+1))
   echo "v$i: $v"
   (
-    d=/tmp/ecckd_var/v$i; mkdir -p $d
+    d=/tmp/ecckd_var/v$i; rm -rf $d; mkdir -p $d
     tf="$v"; of=""
     case "$v" in ALL:*) of="${v#ALL:}"; tf="${v#ALL:}";; esac
-    /opt/rocm/bin/hipcc $BASE -ffp-contract=off $tf -c kernels_tau.hip -o $d/tau.o
+    for s in kernels_gas_fused.hip kernels_tau.hip; do /opt/rocm/bin/hipcc $BASE $tf -c $s -o $d/${s%.*}.o; done
     for s in kernels_planck.hip kernels_rte_lw.hip kernels_rte_sw.hip capi.cpp model.cpp cdf1.cpp; do
-      /opt/rocm/bin/hipcc $BASE -ffp-contract=off $of -c $s -o $d/${s%.*}.o
+      /opt/rocm/bin/hipcc $BASE $of -c $s -o $d/${s%.*}.o
     done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,-rpath,/opt/rocm/lib -o ../../variants_tmp/lib_v$i.so $d/*.o
   ) &
