@@ -193,10 +193,19 @@ def main():
                                 "GBps": b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}
         dom = max(kern, key=lambda n: kern[n][0]) if kern else None
         roofline = None
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01c_hbm_traffic.json")))
+            if ncol == 1000000 and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         if dom:
             ach = per_kernel[dom]["GBps"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": "profiles/r01c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                          "gfx950-corrected)" if traffic else None,
                         "avg_launch_ms": per_kernel[dom]["avg_ms"],
                         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes_per_launch"]}
         total_b = (bpc["tau"] + bpc["planck"] + bpc["rte_lw"]) * ncol

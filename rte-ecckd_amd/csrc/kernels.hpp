@@ -51,10 +51,21 @@ struct TauArgs {
 // Division by a wave-uniform constant, d with its reciprocal (kernels_gas_fused.hip: udiv()).
 struct UDiv { double d, r; int exact; };
 
+// Per-slot view of the gases of a pass for the fused kernel: slot s < nbil is the s-th bilinear
+// gas, slot kTauPassGases is the look_up_table gas.  `vmr` is ALWAYS a valid device address (the
+// load is issued unconditionally, all slots in one round); `use_scalar` picks `scalar` afterwards.
+struct SlotArgs {
+  const double *vmr;
+  long long cs, ls;
+  double scalar, ref;
+  int use_scalar, code;
+};
+
 // Fused gas-optics launch (kernels_gas_fused.hip): the tau arguments plus the Planck side.
 struct FusedArgs {
   TauArgs tau;
-  UDiv ud_dlp, ud_dt, ud_dlv, ud_pdt;   // filled by launch_gas_fused
+  UDiv ud_dlp, ud_dt, ud_dlv, ud_pdt;          // filled by launch_gas_fused
+  SlotArgs slot[kTauPassGases + 1];            // filled by launch_gas_fused
   int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
   int ntp;
   const double *planck;        // (ng,ntp) device

@@ -146,7 +146,7 @@ __device__ __forceinline__ void store_pair(double *arr, long c, long o0, long o1
     out[0] = odd ? recv : v0;
     out[1] = odd ? v1 : recv;
     const long ce = c - (odd ? 1 : 0);
-#ifdef ECCKD_NT_STORES
+#ifndef ECCKD_PLAIN_STORES   // nontemporal: the outputs are written once and read by the next kernel
     __builtin_nontemporal_store(out, reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce));
 #else
     *reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce) = out;
@@ -257,20 +257,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       // ---- setup: one round of global loads ----
       const double p0 = plev0[cc], p1 = plev1[cc];
       const double T = t.tlay[cc + (long)ncol * j];
-      double W[NB];        // per-slot weight (:143-149), 0 for unused slots
-      double vlut = 0.;    // vmr of the look_up_table gas
+      double W[NB];        // per-slot vmr, then weight (:143-149); 0 for unused slots
 #pragma unroll
-      for (int s = 0; s < NB; ++s) {
-        W[s] = 0.;
-        if (s < t.nbil) {
-          const SeqGas &e = t.seq[t.bil_seq[s]];
-          W[s] = e.vmr ? e.vmr[cc * e.cs + j * e.ls] : e.scalar;
-        }
-      }
-      if (t.lut >= 0) {
-        const SeqGas &e = t.seq[t.lut];
-        vlut = e.vmr ? e.vmr[cc * e.cs + j * e.ls] : e.scalar;
-      }
+      for (int s = 0; s < NB; ++s) W[s] = a.slot[s].vmr[cc * a.slot[s].cs + j * a.slot[s].ls];
+      double vlut = a.slot[kTauPassGases].vmr[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
       double Tl0 = 0., Tl1 = 0.;
       if (MODE == MODE_LW && a.tlev) {
         Tl0 = a.tlev[cc + (long)ncol * j];
@@ -298,6 +288,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       int iv0 = 1;
       if (t.lut >= 0) {   // :153-163
         const SeqGas &e = t.seq[t.lut];
+        vlut = a.slot[kTauPassGases].use_scalar ? a.slot[kTauPassGases].scalar : vlut;
         const double log_vmr = log(selmax(vlut, e.mf0));
         double vmr_index = udiv(log_vmr - e.log_mf0, a.ud_dlv);
         vmr_index = 1. + selmax(0., selmin(vmr_index, (double)e.nv - 1.001));
@@ -312,15 +303,12 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < NB; ++s) {
-        if (s < t.nbil) {
-          const SeqGas &e = t.seq[t.bil_seq[s]];
-          double x = e.code == 3 ? simple_weight * (W[s] - e.ref)
-                                 : (e.code == 0 ? simple_weight : simple_weight * W[s]);
-          if (!ANYCLAMP) x = x < 0. ? 0. : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
-          W[s] = x;
-        }
+        const SlotArgs &e = a.slot[s];
+        const double v = e.use_scalar ? e.scalar : W[s];
+        double x = e.code == 3 ? simple_weight * (v - e.ref) : (e.code == 0 ? simple_weight : simple_weight * v);
+        if (!ANYCLAMP) x = x < 0. ? 0. : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
+        W[s] = s < t.nbil ? x : 0.;
       }
-
       PlPoint qlay{0, 0., 0.}, ql0{0, 0., 0.}, ql1{0, 0., 0.};
       if (MODE == MODE_LW) {
         qlay = planck_point(T, a.pt0, a.ud_pdt, ntp, L.SP);
@@ -596,6 +584,16 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   a.ud_dt = make_udiv(t.dt);
   a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1.);
   a.ud_pdt = make_udiv(a.mode == MODE_LW ? a.pdt : 1.);
+  for (int s = 0; s <= kTauPassGases; ++s) {
+    const int k = s < kTauPassGases ? (s < t.nbil ? t.bil_seq[s] : -1) : t.lut;
+    SlotArgs &o = a.slot[s];
+    o = SlotArgs{t.plev, 0, 0, 0., 0., 1, 1};   // unused slot: a harmless load, weight forced to 0
+    if (k >= 0) {
+      const SeqGas &e = t.seq[k];
+      o.scalar = e.scalar; o.ref = e.ref; o.code = e.code;
+      if (e.vmr) { o.vmr = e.vmr; o.cs = e.cs; o.ls = e.ls; o.use_scalar = 0; }
+    }
+  }
   if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;
   if (t.nseq > kTauPassGases) return hipErrorInvalidValue;
   {
