@@ -80,7 +80,13 @@ def main():
     ap.add_argument("--ncol", type=int, default=1000000, help="synthetic columns per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the CPU baseline")
+    ap.add_argument("--lut", choices=["fsck", "rrtmgp"], default="fsck",
+                    help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
+    ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
+                    help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     args = ap.parse_args()
+    if args.mode == "sw":
+        return main_sw(args)
 
     import torch
     import torch.distributed as dist
@@ -101,9 +107,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    lw_file = LW_FILE if args.lut == "fsck" else LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061")
     L = pkg.lib()
     k = pkg.GasOpticsEcckd()
-    err = k.load(LW_FILE, device=local_rank)
+    err = k.load(lw_file, device=local_rank)
     if err:
         raise SystemExit(err)
     ng, ncol, nlay = k.get_ngpt(), args.ncol, NLAY
@@ -133,7 +140,7 @@ def main():
             gc.set_vmr_column(name, percol[name])
         else:
             gc.set_vmr(name, 0.209 if name == "o2" else 0.0)
-    emis = percol["sfc_emis"].reshape(ncol, 1)
+    emis = percol["sfc_emis"].reshape(ncol, 1).expand(ncol, k.get_nband()).contiguous()
 
     op = pkg.OpticalProps1scl()
     op.alloc_1scl(ncol, nlay, k, like=plev)
@@ -213,7 +220,7 @@ def main():
         # spot check of the timed configuration against the CPU oracle (64 columns)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
-        m = oracle.CkdModel(LW_FILE)
+        m = oracle.CkdModel(lw_file)
         cols = synthetic.columns(0, 64, press_min)
         tau, lay, inc, dec, sfc, _ = oracle.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
                                                            synthetic.gas_items(cols), cols["tlev"])
@@ -225,10 +232,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic %d columns x %d layers x %d g-points per GPU, LW fsck-tol0.0161, "
+            "config": {"workload": ("synthetic %d columns x %d layers x %d g-points per GPU, LW " % (ncol, nlay, ng)) + os.path.basename(lw_file)[36:-3] + ", "
                                    "gas_optics + rte_lw (1 angle), fp64, inputs and intermediates HBM-resident; "
                                    "north_star target size (configs[1] is the same workload at 1e5 columns)"
-                                   % (ncol, nlay, ng),
+                                   ,
                        "ncol_per_gpu": ncol, "nlay": nlay, "ngpt": ng, "parallelism": "column-range x%d" % world},
             "roofline": roofline,
             "roofline_pipeline": {"bound": "hbm", "achieved": pipe, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -244,6 +251,99 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_sw(args):
+    """Secondary line: SW wide-tol0.05 (27 g-points), gas_optics (tau, ssa, g) + rte_sw two-stream, fp64,
+    single GPU.  Algorithmic bytes: tau, ssa, g written once and read once = 48 B/cell (+ per-column terms)."""
+    import torch
+    import rte_ecckd_amd as pkg
+    from rte_ecckd_amd import synthetic
+    sw_file = os.path.join(ROOT, "data", "ecckd-1.2_sw_ckd-definition_climate_wide-tol0.05.nc")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    L = pkg.lib()
+    k = pkg.GasOpticsEcckd()
+    err = k.load(sw_file, device=0)
+    if err:
+        raise SystemExit(err)
+    ng, ncol, nlay = k.get_ngpt(), args.ncol, NLAY
+    f64 = dict(dtype=torch.float64, device=dev)
+    plev = torch.empty((nlay + 1, ncol), **f64)
+    tlay = torch.empty((nlay, ncol), **f64)
+    h2o = torch.empty((nlay, ncol), **f64)
+    o3 = torch.empty((nlay, ncol), **f64)
+    percol = {n: torch.empty((ncol,), **f64) for n in ("co2", "ch4", "n2o", "mu0", "albedo")}
+    for c0 in range(0, ncol, 100000):
+        n = min(100000, ncol - c0)
+        cols = synthetic.columns(c0, n, k.get_press_min(), shortwave=True)
+        for dst, key in ((plev, "plev"), (tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
+            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+        for key, dst in percol.items():
+            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+    names = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
+    gc = pkg.GasConcs(names)
+    for name in names:
+        if name in ("h2o", "o3"):
+            gc.set_vmr(name, h2o if name == "h2o" else o3)
+        elif name in percol:
+            gc.set_vmr_column(name, percol[name])
+        else:
+            gc.set_vmr(name, 0.209)
+    op = pkg.OpticalProps2str()
+    op.alloc_2str(ncol, nlay, k, like=plev)
+    toa = torch.empty((ng, ncol), **f64)
+    nband = k.get_nband()
+    alb = percol["albedo"].reshape(ncol, 1).expand(ncol, nband).contiguous()
+    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), **f64), torch.empty((nlay + 1, ncol), **f64))
+
+    def step():
+        e = k.gas_optics(None, plev, tlay, gc, op, toa)
+        if e:
+            raise SystemExit(e)
+        e = pkg.rte_sw(op, True, percol["mu0"], toa, alb, alb, fl)
+        if e:
+            raise SystemExit(e)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    L.ecckd_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.ecckd_prof_enable(0)
+    names_b = C.create_string_buffer(8 * 32)
+    ms = (C.c_double * 8)()
+    cnt = (C.c_longlong * 8)()
+    nk = L.ecckd_prof_report(8, names_b, ms, cnt)
+    kern = {names_b.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): ms[i] / max(cnt[i], 1) for i in range(nk)}
+    cells = ncol * nlay * ng
+    ms_per_step = elapsed / args.steps * 1e3
+    alg = 48.0 * cells + 8.0 * ncol * ((nlay + 1) + 3 * nlay + 5 + 2 * ng + 2 * (nlay + 1))
+    # spot check against the CPU oracle
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    m = oracle.CkdModel(sw_file)
+    cols = synthetic.columns(0, 64, k.get_press_min(), shortwave=True)
+    items = [(n, np.atleast_1d(np.asarray(cols[n], dtype=np.float64)), 0 if np.isscalar(cols[n]) else 1,
+              0 if (np.isscalar(cols[n]) or cols[n].ndim == 1) else 64) for n in names]
+    tau, ssa, g, toa_o, _ = oracle.gas_optics_ext(m, cols["plev"], cols["tlay"], items)
+    a2 = np.repeat(cols["albedo"][None], ng, 0)
+    fu, fd, _ = oracle.rte_sw(tau, ssa, g, cols["mu0"], toa_o, a2, a2)
+    dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].cpu().numpy() - fu))),
+                float(np.max(np.abs(fl.flux_dn[:, :64].cpu().numpy() - fd))))
+    print(json.dumps({
+        "metric": "Mcol*lay*gpt/s SW gas_optics+rte_sw", "value": cells * args.steps / elapsed / 1e6,
+        "unit": "Mcol*lay*gpt/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic %d columns x %d layers x %d g-points, SW wide-tol0.05, gas_optics + rte_sw "
+                               "two-stream, fp64 (BASELINE configs[2])" % (ncol, nlay, ng)},
+        "roofline_pipeline": {"bound": "hbm", "achieved": alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "kernels_avg_ms": kern, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux}), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,13 @@
 //
 // Mapping (gfx950): as the LW solver -- one wave = CW columns x GW=64/CW g-points, lanes that
 // share a column are summed with a wave shuffle butterfly into wave-private LDS accumulators.
-// The adding method needs four per-layer quantities bottom-up and six top-down; round-1
-// version keeps them in a per-wave global scratch ring ([array][layer][lane], 512 B coalesced
-// rows) instead of registers.
+// Two passes per (column, g-point): bottom->top computes the two-stream coefficients ONCE and runs
+// the adding recurrences with the source normalised by the direct beam (which is only known on the
+// way down); top->bottom propagates the direct beam and the fluxes.  The four per-layer and two
+// per-level quantities the second pass needs go through a per-wave global scratch ring
+// ([array][layer][lane], 512 B coalesced rows; 4096 waves x 187 KB): 120 B/cell of traffic in all.
+// (Registers cannot hold them next to a useful occupancy: the coefficient arithmetic is ~300 fp64
+// instructions per cell and needs several waves per SIMD to issue at rate.)
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -22,7 +26,19 @@ __device__ __forceinline__ double gsum(double v) {
   return v;
 }
 
-constexpr int kSwWaves = 2048;
+#ifndef ECCKD_SW_WAVES
+#define ECCKD_SW_WAVES 4096   // 16 waves per CU (121 VGPRs): measured 15 % faster than 2048
+#endif
+#ifndef ECCKD_SW_CW
+#define ECCKD_SW_CW 16
+#endif
+constexpr int kSwWaves = ECCKD_SW_WAVES;
+
+// acc += v by the owner lane only (the other lanes add +0.0): one fire-and-forget ds_add_f64,
+// order-independent result (see kernels_rte_lw.hip).
+__device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
+  __hip_atomic_fetch_add(p, owner ? v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 
 template <int CW>
 __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
@@ -30,15 +46,16 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
   const int lane = threadIdx.x;
   const int cl = lane % CW, gs = lane / CW;
+  const bool owner = gs == 0;
   const int ncol = a.ncol, nlay = a.nlay, ng = a.ng, nlev = nlay + 1;
   double *acc_up = acc, *acc_dn = acc + nlev * CW, *acc_dir = acc + 2 * nlev * CW;
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
   const long lstep = a.top_at_1 ? 1 : -1;
   const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
-  // scratch ring of this wave: 4 layer arrays + 3 level arrays, each [index][64 lanes]
-  double *sc = a.scratch + (long)blockIdx.x * (4L * nlay + 3L * nlev) * 64 + lane;
-  double *sRdif = sc, *sTdif = sc + 64L * nlay, *sX = sc + 128L * nlay, *sSdn = sc + 192L * nlay;
-  double *sAlb = sc + 256L * nlay, *sSrc = sAlb + 64L * nlev, *sDir = sSrc + 64L * nlev;
+  // scratch ring of this wave: 4 layer arrays + 2 level arrays, each [index][64 lanes]
+  double *sc = a.scratch + (long)blockIdx.x * (4L * nlay + 2L * nlev) * 64 + lane;
+  double *sA = sc, *sB = sc + 64L * nlay, *sC = sc + 128L * nlay, *sTn = sc + 192L * nlay;
+  double *sAlb = sc + 256L * nlay, *sSrc = sAlb + 64L * nlev;
   const int ngroups = (ng + GW - 1) / GW;
   const long ntiles = ((long)ncol + CW - 1) / CW;
 
@@ -57,12 +74,17 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
       const double keep = gact ? 1. : 0.;
       const long base = cc + (long)ncol * nlay * gg;
       const int band = a.gpt2band[gg];
-      const double alb_dir = a.alb_dir[band + (long)a.nband * cc];
-      const double alb_dif = a.alb_dif[band + (long)a.nband * cc];
 
-      // ---- pass 1, top -> bottom: two-stream coefficients, direct beam, sources ----
-      double fdir = a.toa[cc + (long)ncol * gg] * mu0;
-      for (int s = 0; s < nlay; ++s) {
+      // ---- pass 1, bottom -> top: two-stream coefficients (sw_two_stream) and the adding
+      // recurrences (albedo, source of upward radiation).  The direct beam is not known yet on the
+      // way up, so the source is carried normalised by the direct flux at its own level:
+      //   src(l) = nsrc(l) * F_dir(l),  F_dir(l+1) = Tnoscat(l) * F_dir(l)
+      // and the three products the downward sweep needs are stored once per layer.
+      double albedo = a.alb_dif[band + (long)a.nband * cc];
+      double nsrc = a.alb_dir[band + (long)a.nband * cc];   // src_sfc = F_dir(sfc) * sfc_alb_dir
+      sAlb[64L * nlay] = albedo;
+      sSrc[64L * nlay] = nsrc;
+      for (int s = nlay - 1; s >= 0; --s) {
         const long q = base + (long)ncol * (lay0 + lstep * s);
         const double tau = a.tau[q], w0 = a.ssa[q], gq = a.g[q];
         const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
@@ -88,45 +110,38 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
         const double Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
                                         (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * Tnoscat -
                                         2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
-        sRdif[64L * s] = Rdif;
-        sTdif[64L * s] = Tdif;
-        sX[64L * s] = Rdir * fdir;     // source_up
-        sSdn[64L * s] = Tdir * fdir;   // source_dn
-        sDir[64L * s] = fdir;
-        fdir = Tnoscat * fdir;
-      }
-      sDir[64L * nlay] = fdir;
-
-      // ---- pass 2, bottom -> top: adding (albedo and source of upward radiation) ----
-      double albedo = alb_dif, src = fdir * alb_dir;
-      sAlb[64L * nlay] = albedo;
-      sSrc[64L * nlay] = src;
-      for (int s = nlay - 1; s >= 0; --s) {
-        const double Rdif = sRdif[64L * s], Tdif = sTdif[64L * s];
-        const double src_up = sX[64L * s], src_dn = sSdn[64L * s];
-        const double denom = 1. / (1. - Rdif * albedo);
-        const double nalb = Rdif + Tdif * Tdif * albedo * denom;
-        src = src_up + Tdif * denom * (src + albedo * src_dn);
-        albedo = nalb;
-        sX[64L * s] = denom;   // source_up is no longer needed
+        const double denom = 1. / (1. - Rdif * albedo);                           // adding, Eq 10
+        sA[64L * s] = Tdif * denom;
+        sB[64L * s] = Rdif * denom;
+        sC[64L * s] = Tdir * denom;
+        sTn[64L * s] = Tnoscat;
+        // Eq 11 divided by F_dir(l): src_up = Rdir*F_dir(l), src_dn = Tdir*F_dir(l), src(l+1) = nsrc*Tnoscat*F_dir(l)
+        nsrc = Rdir + Tdif * denom * (nsrc * Tnoscat + albedo * Tdir);
+        albedo = Rdif + Tdif * Tdif * albedo * denom;                              // Eq 9
         sAlb[64L * s] = albedo;
-        sSrc[64L * s] = src;
+        sSrc[64L * s] = nsrc;
       }
 
-      // ---- pass 3, top -> bottom: fluxes ----
+      // ---- pass 2, top -> bottom: direct beam and fluxes (Eq 12, 13) ----
+      double fdir = a.toa[cc + (long)ncol * gg] * mu0;
       double fdn = 0.;
-      for (int s = 0; s <= nlay; ++s) {
-        if (s > 0)
-          fdn = (sTdif[64L * (s - 1)] * fdn + sRdif[64L * (s - 1)] * sSrc[64L * s] + sSdn[64L * (s - 1)]) *
-                sX[64L * (s - 1)];
-        const double fup = fdn * sAlb[64L * s] + sSrc[64L * s];
-        const double dir = sDir[64L * s];
-        const double vu = gsum<CW>(keep * fup), vd = gsum<CW>(keep * (fdn + dir)), vr = gsum<CW>(keep * dir);
-        if (gs == 0) {
-          acc_up[s * CW + cl] += vu;
-          acc_dn[s * CW + cl] += vd;
-          acc_dir[s * CW + cl] += vr;
-        }
+      {
+        const double fup = fdn * albedo + nsrc * fdir;
+        const double vu = gsum<CW>(keep * fup), vd = gsum<CW>(keep * (fdn + fdir)), vr = gsum<CW>(keep * fdir);
+        acc_add(&acc_up[cl], vu, owner);
+        acc_add(&acc_dn[cl], vd, owner);
+        acc_add(&acc_dir[cl], vr, owner);
+      }
+      for (int s = 0; s < nlay; ++s) {
+        const double fdir_next = sTn[64L * s] * fdir;
+        const double src_next = sSrc[64L * (s + 1)] * fdir_next;
+        fdn = sA[64L * s] * fdn + sB[64L * s] * src_next + sC[64L * s] * fdir;
+        const double fup = fdn * sAlb[64L * (s + 1)] + src_next;
+        fdir = fdir_next;
+        const double vu = gsum<CW>(keep * fup), vd = gsum<CW>(keep * (fdn + fdir)), vr = gsum<CW>(keep * fdir);
+        acc_add(&acc_up[(s + 1) * CW + cl], vu, owner);
+        acc_add(&acc_dn[(s + 1) * CW + cl], vd, owner);
+        acc_add(&acc_dir[(s + 1) * CW + cl], vr, owner);
       }
     }
 
@@ -151,14 +166,14 @@ __global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *to
 
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
   (void)ng;
-  long tiles = ((long)ncol + 15) / 16;
+  long tiles = ((long)ncol + ECCKD_SW_CW - 1) / ECCKD_SW_CW;
   if (tiles > kSwWaves) tiles = kSwWaves;
-  return sizeof(double) * (size_t)(4L * nlay + 3L * (nlay + 1)) * 64 * (size_t)tiles;
+  return sizeof(double) * (size_t)(4L * nlay + 2L * (nlay + 1)) * 64 * (size_t)tiles;
 }
 
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
-  constexpr int CW = 16;
+  constexpr int CW = ECCKD_SW_CW;
   auto k = rte_sw_kernel<CW>;
   const size_t lds = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;

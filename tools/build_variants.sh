@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds experimental variants of the library next to the product .so so that one gpurun call can
 # A/B them (tools/ab.py):   tools/build_variants.sh "<extra hipcc flags>" ...
-# Flags apply to the gas-optics kernels (kernels_gas_fused.hip, kernels_tau.hip); a leading "ALL:"
+# Flags apply to kernels_gas_fused.hip, kernels_tau.hip and kernels_rte_lw.hip; a leading "ALL:"
 # applies them to every source.
 set -e
 cd "$(dirname "$0")/../rte-ecckd_amd/csrc"
@@ -15,8 +15,8 @@ for v in "$@"; do
     d=/tmp/ecckd_var/v$i; rm -rf $d; mkdir -p $d
     tf="$v"; of=""
     case "$v" in ALL:*) of="${v#ALL:}"; tf="${v#ALL:}";; esac
-    for s in kernels_gas_fused.hip kernels_tau.hip; do /opt/rocm/bin/hipcc $BASE $tf -c $s -o $d/${s%.*}.o; done
-    for s in kernels_planck.hip kernels_rte_lw.hip kernels_rte_sw.hip capi.cpp model.cpp cdf1.cpp; do
+    for s in kernels_gas_fused.hip kernels_tau.hip kernels_rte_lw.hip kernels_rte_sw.hip; do /opt/rocm/bin/hipcc $BASE $tf -c $s -o $d/${s%.*}.o; done
+    for s in kernels_planck.hip capi.cpp model.cpp cdf1.cpp; do
       /opt/rocm/bin/hipcc $BASE $of -c $s -o $d/${s%.*}.o
     done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,-rpath,/opt/rocm/lib -o ../../variants_tmp/lib_v$i.so $d/*.o
