@@ -103,8 +103,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ   # launched through torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lw_file = LW_FILE if args.lut == "fsck" else LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061")
@@ -157,7 +159,7 @@ def main():
             raise SystemExit(e)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
@@ -183,7 +185,7 @@ def main():
     for i in range(nk):
         kern[names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode()] = (ms[i] / max(cnt[i], 1), int(cnt[i]))
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -249,7 +251,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -34,8 +34,9 @@ HOST, DEVICE = 0, 1
 NAME_LEN = 32
 
 _SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_sw.hip",
-            "capi.cpp", "model.cpp", "cdf1.cpp"]
-_HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h")]
+            "capi.cpp", "nc_capi.cpp", "model.cpp", "cdf1.cpp"]
+_HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h"),
+            os.path.join("..", "..", "include", "ecckd_nc.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -57,37 +58,47 @@ def build(force=False, verbose=False):
 
 
 FORTRAN_DIR = os.path.join(_HERE, "fortran")
-FORTRAN_DRIVER = os.path.join(FORTRAN_DIR, "build", "ecckd_driver")
-_FORTRAN_SOURCES = ["mo_rte_min.F90", "gas_optics_ecckd.F90", "mo_rte_solvers.F90", "ecckd_driver.F90"]
+FORTRAN_BUILD = os.path.join(FORTRAN_DIR, "build")
+FORTRAN_DRIVER = os.path.join(FORTRAN_BUILD, "ecckd_driver")
+RFMIP_LW = os.path.join(FORTRAN_BUILD, "ecckd_rfmip_lw")
+RFMIP_SW = os.path.join(FORTRAN_BUILD, "ecckd_rfmip_sw")
+_FORTRAN_MODULES = ["mo_rte_min.F90", "gas_optics_ecckd.F90", "mo_rte_solvers.F90", "rfmip_support.F90"]
+_FORTRAN_PROGRAMS = [("ecckd_driver", "ecckd_driver.F90", []), ("ecckd_rfmip_lw", "ecckd_rfmip.F90", []),
+                     ("ecckd_rfmip_sw", "ecckd_rfmip.F90", ["-DSHORTWAVE"])]
 
 
 def build_fortran(force=False, verbose=False):
-    """Compile the Fortran drop-in module, the solver shims and the host driver with amdflang and
-    link them against librte_ecckd_hip.so.  Returns the driver path, or None if no Fortran compiler
-    is installed (the C ABI and the Python mirror do not need one)."""
+    """Compile the Fortran drop-in module, the solver shims, the RFMIP support modules and the host
+    programs (ecckd_driver, ecckd_rfmip_lw, ecckd_rfmip_sw) with amdflang and link them against
+    librte_ecckd_hip.so.  Returns the path of ecckd_driver, or None if no Fortran compiler is
+    installed (the C ABI and the Python mirror do not need one)."""
     fc = os.environ.get("FC", "/opt/rocm/bin/amdflang")
     if not os.path.exists(fc):
         return None
-    srcs = [os.path.join(FORTRAN_DIR, s) for s in _FORTRAN_SOURCES]
-    bdir = os.path.dirname(FORTRAN_DRIVER)
-    if not force and os.path.exists(FORTRAN_DRIVER):
-        t = os.path.getmtime(FORTRAN_DRIVER)
+    srcs = [os.path.join(FORTRAN_DIR, s) for s in _FORTRAN_MODULES + sorted({p[1] for p in _FORTRAN_PROGRAMS})]
+    exes = [os.path.join(FORTRAN_BUILD, p[0]) for p in _FORTRAN_PROGRAMS]
+    if not force and all(os.path.exists(e) for e in exes):
+        t = min(os.path.getmtime(e) for e in exes)
         if all(os.path.getmtime(d) <= t for d in srcs + [LIB_PATH]):
             return FORTRAN_DRIVER
-    os.makedirs(bdir, exist_ok=True)
-    objs = []
-    for s in srcs:
-        o = os.path.join(bdir, os.path.basename(s)[:-4] + ".o")
-        cmd = [fc, "-O2", "-module-dir", bdir, "-I" + bdir, "-c", s, "-o", o]
+    os.makedirs(FORTRAN_BUILD, exist_ok=True)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+
+    objs = []
+    for s in _FORTRAN_MODULES:
+        o = os.path.join(FORTRAN_BUILD, s[:-4] + ".o")
+        run([fc, "-O2", "-module-dir", FORTRAN_BUILD, "-I" + FORTRAN_BUILD, "-c", os.path.join(FORTRAN_DIR, s), "-o", o])
         objs.append(o)
-    cmd = [fc, "-o", FORTRAN_DRIVER] + objs + ["-L" + _HERE, "-lrte_ecckd_hip", "-Wl,-rpath,$ORIGIN/../..",
-                                               "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    for exe, src, flags in _FORTRAN_PROGRAMS:
+        o = os.path.join(FORTRAN_BUILD, exe + ".o")
+        run([fc, "-O2", "-cpp"] + flags + ["-module-dir", FORTRAN_BUILD, "-I" + FORTRAN_BUILD, "-c",
+                                           os.path.join(FORTRAN_DIR, src), "-o", o])
+        run([fc, "-o", os.path.join(FORTRAN_BUILD, exe), o] + objs +
+            ["-L" + _HERE, "-lrte_ecckd_hip", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"])
     return FORTRAN_DRIVER
 
 

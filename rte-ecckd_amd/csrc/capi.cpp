@@ -22,6 +22,13 @@ int fail(const std::string &msg) {
   g_err = msg;
   return 1;
 }
+}  // namespace
+
+namespace ecckd {
+int set_last_error(const std::string &msg) { return fail(msg); }   // for nc_capi.cpp
+}  // namespace ecckd
+
+namespace {
 
 #define HIPCHK(expr)                                                                     \
   do {                                                                                   \
