@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the CPU baseline")
     ap.add_argument("--lut", choices=["fsck", "rrtmgp"], default="fsck",
                     help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f64 = headline; f32 = single-precision flavour of the LW path (BASELINE configs[4] sweep)")
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     args = ap.parse_args()
@@ -119,7 +121,8 @@ def main():
     press_min = k.get_press_min()
 
     # ---- synthetic inputs, generated in chunks on the host, resident on the device ----
-    f64 = dict(dtype=torch.float64, device=dev)
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    f64 = dict(dtype=tdt, device=dev)
     plev = torch.empty((nlay + 1, ncol), **f64)
     tlev = torch.empty((nlay + 1, ncol), **f64)
     tlay = torch.empty((nlay, ncol), **f64)
@@ -131,9 +134,9 @@ def main():
         n = min(chunk, ncol - c0)
         cols = synthetic.columns(rank * ncol + c0, n, press_min)
         for dst, key in ((plev, "plev"), (tlev, "tlev"), (tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
-            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
         for key, dst in percol.items():
-            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
     gc = pkg.GasConcs(synthetic.GAS_ORDER)
     for name in synthetic.GAS_ORDER:
         if name in ("h2o", "o3"):
@@ -195,6 +198,9 @@ def main():
         value = world * cells_per_gpu * args.steps / elapsed / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         bpc = algorithmic_bytes_per_column(ng)
+        if args.dtype == "f32":
+            bpc = {kk: vv // 2 for kk, vv in bpc.items()}
+            bpc["gas_lw_fused_f32"] = bpc["gas_lw_fused"]
         per_kernel = {}
         for name, (avg_ms, n) in kern.items():
             b = bpc.get(name, 0) * ncol
@@ -205,7 +211,7 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01c_hbm_traffic.json")))
-            if ncol == 1000000 and dom in tj["kernels"]:
+            if ncol == 1000000 and args.dtype == "f64" and args.lut == "fsck" and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -227,15 +233,15 @@ def main():
         tau, lay, inc, dec, sfc, _ = oracle.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
                                                            synthetic.gas_items(cols), cols["tlev"])
         fu, fd = oracle.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None, :], ng, 0), sfc)
-        dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].cpu().numpy() - fu))),
-                    float(np.max(np.abs(fl.flux_dn[:, :64].cpu().numpy() - fd))))
+        dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].double().cpu().numpy() - fu))),
+                    float(np.max(np.abs(fl.flux_dn[:, :64].double().cpu().numpy() - fd))))
         out = {
             "metric": "Mcol*lay*gpt/s LW gas_optics+rte_lw", "value": value, "unit": "Mcol*lay*gpt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": ("synthetic %d columns x %d layers x %d g-points per GPU, LW " % (ncol, nlay, ng)) + os.path.basename(lw_file)[36:-3] + ", "
-                                   "gas_optics + rte_lw (1 angle), fp64, inputs and intermediates HBM-resident; "
+                                   "gas_optics + rte_lw (1 angle), " + ("fp64" if args.dtype == "f64" else "fp32") + ", inputs and intermediates HBM-resident; "
                                    "north_star target size (configs[1] is the same workload at 1e5 columns)"
                                    ,
                        "ncol_per_gpu": ncol, "nlay": nlay, "ngpt": ng, "parallelism": "column-range x%d" % world},

@@ -135,6 +135,18 @@ int ecckd_gas_optics_lw(const ecckd_model_t *model, int ncol, int nlay, const do
                         double *lev_source_inc, double *lev_source_dec, double *sfc_source,
                         int memspace, void *stream);
 
+/* Single-precision flavour (a host built with RTE-RRTMGP's RTE_USE_SP, i.e. wp = real32): every
+ * data array is float, arithmetic is float.  Implemented for the fused fast longwave path (one
+ * pass, Planck table next to >= 3 slab rows: true for all ecCKD files in single precision); other
+ * cases fail with a message.  vmr_scalar stays double (values, not arrays). */
+int ecckd_gas_optics_lw_f32(const ecckd_model_t *model, int ncol, int nlay, const float *plev,
+                            const float *tlay, const float *tsfc, const float *tlev, int ngas,
+                            const char *gas_names, const float *const *vmr,
+                            const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                            const double *vmr_scalar, float *tau, float *lay_source,
+                            float *lev_source_inc, float *lev_source_dec, float *sfc_source,
+                            int memspace, void *stream);
+
 /* gas_optics_ext (:431-473): tau, ssa, g are (ncol,nlay,ngpt); toa_src is (ncol,ngpt).
  * ssa == NULL or g == NULL stands for an optical_props that is not ty_optical_props_2str:
  * tau (gas + Rayleigh) is written and the call fails with
@@ -159,6 +171,13 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
                  const double *lev_source_dec, const double *sfc_source, int nband,
                  const int *band2gpt, const double *sfc_emis, double *flux_up, double *flux_dn,
                  int memspace, void *stream);
+
+/* Single-precision flavour of ecckd_rte_lw. */
+int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                     const float *tau, const float *lay_source, const float *lev_source_inc,
+                     const float *lev_source_dec, const float *sfc_source, int nband,
+                     const int *band2gpt, const float *sfc_emis, float *flux_up, float *flux_dn,
+                     int memspace, void *stream);
 
 /* Two-stream + adding SW.  mu0(ncol), toa_flux(ncol,ngpt), sfc_alb_dir/dif(nband,ncol).
  * flux_dn includes the direct beam; flux_dir (ncol,nlay+1) may be NULL. */

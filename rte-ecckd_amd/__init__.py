@@ -171,19 +171,30 @@ def _space_of(arrays):
     return DEVICE
 
 
-def _ptr(a, shape=None, what="array"):
-    """Data pointer of a C-contiguous float64 array (numpy or torch)."""
+def _is_f32(a):
+    """True for float32 arrays/tensors (the single-precision flavour of the entry points)."""
     if a is None:
-        return None
+        return False
     if _is_torch(a):
         import torch
-        if a.dtype != torch.float64 or not a.is_contiguous():
-            raise TypeError(what + ": need a contiguous float64 tensor")
+        return a.dtype == torch.float32
+    return isinstance(a, np.ndarray) and a.dtype == np.float32
+
+
+def _ptr(a, shape=None, what="array", f32=False):
+    """Data pointer of a C-contiguous float64 (or, with f32, float32) array (numpy or torch)."""
+    if a is None:
+        return None
+    want = "float32" if f32 else "float64"
+    if _is_torch(a):
+        import torch
+        if a.dtype != (torch.float32 if f32 else torch.float64) or not a.is_contiguous():
+            raise TypeError(what + ": need a contiguous " + want + " tensor")
         if shape is not None and tuple(a.shape) != tuple(shape):
             raise ValueError("%s: shape %s, expected %s" % (what, tuple(a.shape), tuple(shape)))
         return C.c_void_p(a.data_ptr())
-    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
-        raise TypeError(what + ": need a C-contiguous float64 ndarray")
+    if not isinstance(a, np.ndarray) or a.dtype != (np.float32 if f32 else np.float64) or not a.flags.c_contiguous:
+        raise TypeError(what + ": need a C-contiguous " + want + " ndarray")
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError("%s: shape %s, expected %s" % (what, a.shape, tuple(shape)))
     return C.c_void_p(a.ctypes.data)
@@ -197,10 +208,11 @@ def _stream(space):
 
 
 def _empty_like_space(shape, like):
+    """Uninitialised array in the memory space (and precision, if float32) of `like`."""
     if _is_torch(like):
         import torch
-        return torch.empty(shape, dtype=torch.float64, device=like.device)
-    return np.empty(shape, dtype=np.float64)
+        return torch.empty(shape, dtype=torch.float32 if _is_f32(like) else torch.float64, device=like.device)
+    return np.empty(shape, dtype=np.float32 if _is_f32(like) else np.float64)
 
 
 # ------------------------------------------------------------------------------------------
@@ -466,7 +478,7 @@ class GasOpticsEcckd:
         return lib().ecckd_model_get_device(self._need())
 
     # -- gas_optics ---------------------------------------------------------------------
-    def _gas_args(self, gas_desc, ncol, nlay, space):
+    def _gas_args(self, gas_desc, ncol, nlay, space, f32=False):
         ent = gas_desc.entries(ncol, nlay)
         n = len(ent)
         names = b"".join(e[0].encode().ljust(NAME_LEN, b" ") for e in ent)
@@ -478,7 +490,7 @@ class GasOpticsEcckd:
             else:
                 if (_is_torch(e[1]) and e[1].is_cuda) != (space == DEVICE):
                     raise TypeError("gas " + e[0] + ": vmr array is not in the same memory space as the inputs")
-                p = _ptr(e[1], what="vmr of " + e[0])
+                p = _ptr(e[1], what="vmr of " + e[0], f32=f32)
                 keep.append(e[1])
                 ptrs[i] = p.value
         cs = (C.c_longlong * max(n, 1))(*[e[2] for e in ent])
@@ -496,21 +508,23 @@ class GasOpticsEcckd:
 
     def gas_optics_int(self, play, plev, tlay, tsfc, gas_desc, optical_props, sources, col_dry=None,
                        tlev=None):
+        """float64 arrays -> ecckd_gas_optics_lw; float32 arrays -> ecckd_gas_optics_lw_f32."""
         nlay, ncol = tlay.shape
         ng = self.get_ngpt()
+        f32 = _is_f32(plev)
         try:
             space = _space_of([plev, tlay, tsfc, tlev, optical_props.tau, sources.lay_source])
-            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space, f32)
         except KeyError as e:
             return str(e.args[0])
-        rc = lib().ecckd_gas_optics_lw(
-            self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"), _ptr(tlay, (nlay, ncol), "tlay"),
-            _ptr(tsfc, (ncol,), "tsfc"), _ptr(tlev, (nlay + 1, ncol), "tlev"), n, names, ptrs, cs, ls, sc,
-            _ptr(optical_props.tau, (ng, nlay, ncol), "tau"),
-            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
-            _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
-            _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
-            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
+        fn = lib().ecckd_gas_optics_lw_f32 if f32 else lib().ecckd_gas_optics_lw
+        P = lambda a, shape, what: _ptr(a, shape, what, f32)
+        rc = fn(self._need(), ncol, nlay, P(plev, (nlay + 1, ncol), "plev"), P(tlay, (nlay, ncol), "tlay"),
+                P(tsfc, (ncol,), "tsfc"), P(tlev, (nlay + 1, ncol), "tlev"), n, names, ptrs, cs, ls, sc,
+                P(optical_props.tau, (ng, nlay, ncol), "tau"), P(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+                P(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+                P(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+                P(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
         return last_error() if rc else ""
 
     def gas_optics_ext(self, play, plev, tlay, gas_desc, optical_props, toa_src, col_dry=None):
@@ -542,20 +556,23 @@ def _device_of(a):
 
 def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1, device=None):
     """``rte_lw(optical_props, top_at_1, sources, sfc_emis(nband,ncol), fluxes, n_gauss_angles=)``
-    (ecckd_rfmip_lw.F90:130-135).  ``sfc_emis`` is ``(ncol, nband)`` in numpy order."""
+    (ecckd_rfmip_lw.F90:130-135).  ``sfc_emis`` is ``(ncol, nband)`` in numpy order.  float32 arrays
+    take the single-precision entry point."""
     ng, nlay, ncol = optical_props.tau.shape
     b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
     nband = b2g.shape[0]
+    f32 = _is_f32(optical_props.tau)
     space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, fluxes.flux_up, fluxes.flux_dn])
     dev = _device_of(optical_props.tau) if device is None else device
-    rc = lib().ecckd_rte_lw(
-        int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles),
-        _ptr(optical_props.tau), _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
-        _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
-        _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
-        _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
-        _ptr(sfc_emis, (ncol, nband), "sfc_emis"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
-        _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"), space, _stream(space))
+    fn = lib().ecckd_rte_lw_f32 if f32 else lib().ecckd_rte_lw
+    P = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
+    rc = fn(int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), P(optical_props.tau),
+            P(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            P(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            P(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            P(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
+            P(sfc_emis, (ncol, nband), "sfc_emis"), P(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+            P(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"), space, _stream(space))
     return last_error() if rc else ""
 
 

@@ -62,6 +62,16 @@ Arena g_scratch_arena[16];   // generic-nlay solver scratch (device flavours too
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// Single precision: the *_f32 entry points set this for the duration of the call; every staging
+// helper below sizes its copies with esz() and the kernels are launched with f32 = 1.  Data pointers
+// keep their `double *` static type on the way through (they are only passed on, never indexed).
+thread_local int g_f32 = 0;
+size_t esz() { return g_f32 ? sizeof(float) : sizeof(double); }
+struct F32Scope {
+  F32Scope() { g_f32 = 1; }
+  ~F32Scope() { g_f32 = 0; }
+};
+
 // Arithmetic mode (ecckd_set_arithmetic): 0 = fast (fused kernel, re-associated FMAs),
 // 1 = reference order (kernels_tau.hip + kernels_planck.hip, bit-faithful expression order).
 int g_arith = 0;
@@ -95,9 +105,9 @@ struct Bump {
   char *base;
   size_t off = 0;
   explicit Bump(void *b) : base(static_cast<char *>(b)) {}
-  double *take(size_t ndoubles) {
+  double *take(size_t nelem) {
     double *r = reinterpret_cast<double *>(base + off);
-    off += align256(ndoubles * sizeof(double));
+    off += align256(nelem * esz());
     return r;
   }
 };
@@ -141,7 +151,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     const ecckd_model::Gas &t = m->gas[i];
     if (t.composite_only && !first_calc) continue;   // :365-367
     SeqGas e{};
-    e.coef = m->dbuf + t.dev_off;
+    e.coef = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + t.dev_off) : m->dbuf + t.dev_off;
     e.vmr = gd.vmr ? gd.vmr[j] : nullptr;
     e.cs = gd.cs ? gd.cs[j] : 0;
     e.ls = gd.ls ? gd.ls[j] : 0;
@@ -170,12 +180,13 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     TauArgs &a = fa.tau;
     a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.np = m->np; a.nt = m->nt;
     a.plev = plev; a.tlay = tlay;
-    a.temperature = m->dbuf + m->off_temperature;
+    a.temperature = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_temperature) : m->dbuf + m->off_temperature;
     a.lp0 = m->log_pressure[0];                               // :104
     a.dlp = m->log_pressure[1] - m->log_pressure[0];          // :105
     a.dt = m->temperature[m->np] - m->temperature[0];         // :106 T(1,2)-T(1,1)
     // :107  1./(gravity*0.001*dry_air_molar_mass) with default-real literals (:51-52)
     a.gw = 1. / ((double)9.80665f * (double)0.001f * (double)28.970f);
+    if (g_f32) a.gw = (double)(1.f / (9.80665f * 0.001f * 28.970f));   // the same expression with wp = float
     a.lut = -1;
     a.nbil = 0;
     a.nseq = 0;
@@ -207,10 +218,10 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
       int pass_clamp = 0;
       for (int k = 0; k < a.nseq; ++k) pass_clamp |= a.seq[k].clamp;
       if (pl && first_pass && !sw &&
-          fused_slab_rows(a.ng, a.np, a.nt, a.nbil, nv_lut, m->ntp, 3, pass_clamp) > 0) {
+          fused_slab_rows(a.ng, a.np, a.nt, a.nbil, nv_lut, m->ntp, 3, pass_clamp, g_f32) > 0) {
         fa.mode = 1;
         fa.ntp = m->ntp;
-        fa.planck = m->dbuf + m->off_planck;
+        fa.planck = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_planck) : m->dbuf + m->off_planck;
         fa.pt0 = m->temperature_planck[0];                                  // :272
         fa.pdt = m->temperature_planck[1] - m->temperature_planck[0];      // :271
         fa.tlev = pl->tlev; fa.tsfc = pl->tsfc;
@@ -218,9 +229,14 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
         fa.lev_source_dec = pl->lev_dec; fa.sfc_source = pl->sfc_source;
         if (planck_done) *planck_done = true;
       }
-      ProfScope prof(fa.mode == 1 ? "gas_lw_fused" : "tau", stream);
+      fa.f32 = g_f32;
+      if (g_f32 && (fa.mode != 1 || !last))
+        return fail("ecckd: single precision is implemented for the fused longwave gas optics only (this model/"
+                    "gas list needs the multi-pass or unfused path)");
+      ProfScope prof(fa.mode == 1 ? (g_f32 ? "gas_lw_fused_f32" : "gas_lw_fused") : "tau", stream);
       HIPCHK(launch_gas_fused(fa, stream));
     } else {
+      if (g_f32) return fail("ecckd: single precision needs the fast arithmetic mode (ecckd_set_arithmetic(0))");
       ProfScope prof("tau", stream);
       HIPCHK(launch_tau(a, stream));
     }
@@ -248,7 +264,7 @@ struct StagedGases {
 };
 size_t staged_gas_bytes(const GasDesc &gd, int ncol, int nlay) {
   size_t b = 0;
-  for (int j = 0; j < gd.ngas; ++j) b += align256(vmr_extent(gd, j, ncol, nlay) * sizeof(double));
+  for (int j = 0; j < gd.ngas; ++j) b += align256(vmr_extent(gd, j, ncol, nlay) * esz());
   return b;
 }
 int stage_gases(const GasDesc &gd, int ncol, int nlay, Bump &bump, hipStream_t s, StagedGases &out) {
@@ -257,7 +273,7 @@ int stage_gases(const GasDesc &gd, int ncol, int nlay, Bump &bump, hipStream_t s
     const size_t n = vmr_extent(gd, j, ncol, nlay);
     if (!n) continue;
     double *d = bump.take(n);
-    HIPCHK(hipMemcpyAsync(d, gd.vmr[j], n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d, gd.vmr[j], n * esz(), hipMemcpyHostToDevice, s));
     out.ptr[j] = d;
   }
   out.gd = gd;
@@ -266,11 +282,11 @@ int stage_gases(const GasDesc &gd, int ncol, int nlay, Bump &bump, hipStream_t s
 }
 
 int h2d(double *d, const double *h, size_t n, hipStream_t s) {
-  HIPCHK(hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d, h, n * esz(), hipMemcpyHostToDevice, s));
   return 0;
 }
 int d2h(double *h, const double *d, size_t n, hipStream_t s) {
-  HIPCHK(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h, d, n * esz(), hipMemcpyDeviceToHost, s));
   return 0;
 }
 
@@ -460,6 +476,11 @@ int ecckd_model_finalize(ecckd_model_t *m, int device) {
   }
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->dbuf), host.size() * sizeof(double)));
   HIPCHK(hipMemcpy(m->dbuf, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+  {   // the same image rounded to float, for the single-precision entry points
+    std::vector<float> hostf(host.begin(), host.end());
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->dbuf32), hostf.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(m->dbuf32, hostf.data(), hostf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
   m->device = device;
   m->finalized = true;
@@ -491,6 +512,7 @@ void ecckd_model_destroy(ecckd_model_t *m) {
     if (m->host_stream) (void)hipStreamDestroy(m->host_stream);
     if (m->arena) (void)hipFree(m->arena);
     if (m->dbuf) (void)hipFree(m->dbuf);
+    if (m->dbuf32) (void)hipFree(m->dbuf32);
   }
   delete m;
 }
@@ -546,6 +568,7 @@ static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const dou
   if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, false, nullptr, nullptr, &pl, &planck_done, stream))
     return 1;   // :401
   if (planck_done) return 0;
+  if (g_f32) return fail("ecckd: single precision is implemented for the fused longwave gas optics only");
   ecckd::PlanckArgs p{};
   p.ncol = ncol; p.nlay = nlay; p.ng = m->ng; p.ntp = m->ntp;
   p.planck = m->dbuf + m->off_planck;
@@ -589,8 +612,8 @@ int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double
   ecckd_model *mm = const_cast<ecckd_model *>(m);
   std::lock_guard<std::mutex> lock(mm->mu);
   hipStream_t s = mm->host_stream;
-  size_t need = align256(n2l * 8) * 2 + align256(n2 * 8) + align256((size_t)ncol * 8) +
-                staged_gas_bytes(gd, ncol, nlay) + align256(n3 * 8) * 4 + align256((size_t)ncol * m->ng * 8);
+  size_t need = align256(n2l * esz()) * 2 + align256(n2 * esz()) + align256((size_t)ncol * esz()) +
+                staged_gas_bytes(gd, ncol, nlay) + align256(n3 * esz()) * 4 + align256((size_t)ncol * m->ng * esz());
   if (need > mm->arena_bytes) {
     if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
     HIPCHK(hipMalloc(&mm->arena, need));
@@ -613,6 +636,21 @@ int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double
   if (tlev && (d2h(lev_source_inc, d_inc, n3, s) || d2h(lev_source_dec, d_dec, n3, s))) return 1;
   HIPCHK(hipStreamSynchronize(s));
   return tlev ? 0 : fail("tlev is required for ecckd");
+}
+
+int ecckd_gas_optics_lw_f32(const ecckd_model_t *m, int ncol, int nlay, const float *plev, const float *tlay,
+                            const float *tsfc, const float *tlev, int ngas, const char *gas_names,
+                            const float *const *vmr, const long long *vmr_col_stride,
+                            const long long *vmr_lay_stride, const double *vmr_scalar, float *tau,
+                            float *lay_source, float *lev_source_inc, float *lev_source_dec,
+                            float *sfc_source, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_gas_optics_lw(m, ncol, nlay, c(plev), c(tlay), c(tsfc), c(tlev), ngas, gas_names,
+                             reinterpret_cast<const double *const *>(vmr), vmr_col_stride, vmr_lay_stride,
+                             vmr_scalar, w(tau), w(lay_source), w(lev_source_inc), w(lev_source_dec),
+                             w(sfc_source), memspace, stream);
 }
 
 static int gas_optics_sw_dev(const ecckd_model *m, int ncol, int nlay, const double *plev,
@@ -653,8 +691,8 @@ int ecckd_gas_optics_sw(const ecckd_model_t *m, int ncol, int nlay, const double
   ecckd_model *mm = const_cast<ecckd_model *>(m);
   std::lock_guard<std::mutex> lock(mm->mu);
   hipStream_t s = mm->host_stream;
-  size_t need = align256(n2l * 8) + align256(n2 * 8) + staged_gas_bytes(gd, ncol, nlay) +
-                align256(n3 * 8) * 3 + align256((size_t)ncol * m->ng * 8);
+  size_t need = align256(n2l * esz()) + align256(n2 * esz()) + staged_gas_bytes(gd, ncol, nlay) +
+                align256(n3 * esz()) * 3 + align256((size_t)ncol * m->ng * esz());
   if (need > mm->arena_bytes) {
     if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
     HIPCHK(hipMalloc(&mm->arena, need));
@@ -714,6 +752,7 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   if (ncol == 0) return 0;
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
   a.nband = nband;
+  a.f32 = g_f32;
   for (int k = 0; k < n_gauss_angles; ++k) {
     a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
     a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
@@ -741,8 +780,8 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
   Arena &ar = g_solver_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
-  const size_t need = align256(n3 * 8) * 4 + align256((size_t)ncol * ngpt * 8) +
-                      align256((size_t)ncol * nband * 8) + align256(n2l * 8) * 2;
+  const size_t need = align256(n3 * esz()) * 4 + align256((size_t)ncol * ngpt * esz()) +
+                      align256((size_t)ncol * nband * esz()) + align256(n2l * esz()) * 2;
   if (ar.ensure(need)) return 1;
   Bump b(ar.p);
   double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
@@ -759,6 +798,18 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
   return 0;
+}
+
+int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles, const float *tau,
+                     const float *lay_source, const float *lev_source_inc, const float *lev_source_dec,
+                     const float *sfc_source, int nband, const int *band2gpt, const float *sfc_emis,
+                     float *flux_up, float *flux_dn, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_rte_lw(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, c(tau), c(lay_source), c(lev_source_inc),
+                      c(lev_source_dec), c(sfc_source), nband, band2gpt, c(sfc_emis), w(flux_up), w(flux_dn),
+                      memspace, stream);
 }
 
 int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
@@ -797,8 +848,8 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
   Arena &ar = g_solver_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
-  const size_t need = align256(n3 * 8) * 3 + align256((size_t)ncol * 8) + align256((size_t)ncol * ngpt * 8) +
-                      align256((size_t)ncol * nband * 8) * 2 + align256(n2l * 8) * 3;
+  const size_t need = align256(n3 * esz()) * 3 + align256((size_t)ncol * esz()) + align256((size_t)ncol * ngpt * esz()) +
+                      align256((size_t)ncol * nband * esz()) * 2 + align256(n2l * esz()) * 3;
   if (ar.ensure(need)) return 1;
   Bump b(ar.p);
   double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3), *d_mu0 = b.take(ncol);

@@ -66,6 +66,7 @@ struct FusedArgs {
   TauArgs tau;
   UDiv ud_dlp, ud_dt, ud_dlv, ud_pdt;          // filled by launch_gas_fused
   SlotArgs slot[kTauPassGases + 1];            // filled by launch_gas_fused
+  int f32;                     // 1: every data pointer addresses float arrays (LW fused path only)
   int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
   int ntp;
   const double *planck;        // (ng,ntp) device
@@ -92,6 +93,7 @@ struct RteLwArgs {
   unsigned char gpt2band[256]; // 0-based band of each g-point
   double *flux_up, *flux_dn;
   double *scratch;             // generic-nlay path only
+  int f32;                     // 1: the data pointers address float arrays
 };
 
 struct RteSwArgs {
@@ -111,7 +113,7 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp, int f32);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);

@@ -42,8 +42,8 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kSeg = 8;    // tiles between two slab-range checks (block barriers)
 constexpr int kSpan = ECCKD_FUSED_SPAN;
 
-__device__ __forceinline__ double selmin(double a, double b) { return a < b ? a : b; }
-__device__ __forceinline__ double selmax(double a, double b) { return a > b ? a : b; }
+template <typename real> __device__ __forceinline__ real selmin(real a, real b) { return a < b ? a : b; }
+template <typename real> __device__ __forceinline__ real selmax(real a, real b) { return a > b ? a : b; }
 
 struct FLayout {
   int tb, red, bil, SB, lut, SL, pl, SP, total;
@@ -75,48 +75,56 @@ __host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, i
 // correction step returns the correctly rounded quotient, i.e. exactly what `x / d` returns, in
 // 3 instructions instead of the ~30 of the IEEE division sequence.  (Precondition checked on the
 // host: d finite, non-zero, significand not all ones; otherwise exact is 0 and `/` is used.)
-__device__ __forceinline__ double udiv(double x, const UDiv &u) {
+template <typename real> struct UDivT { real d, r; int exact; };
+template <typename real> __device__ __forceinline__ UDivT<real> make_udiv_t(const UDiv &u) {
+  UDivT<real> o;
+  o.d = (real)u.d;
+  o.r = real(1) / o.d;   // correctly rounded reciprocal in the working precision
+  o.exact = u.exact;
+  return o;
+}
+template <typename real> __device__ __forceinline__ real udiv(real x, const UDivT<real> &u) {
   if (!u.exact) return x / u.d;
-  const double q = x * u.r;
-  const double rem = fma(-q, u.d, x);
+  const real q = x * u.r;
+  const real rem = fma(-q, u.d, x);
   return fma(rem, u.r, q);
 }
 
-struct PPoint { int ip0; double pw0, pw1; };
-__device__ __forceinline__ PPoint pressure_point(double p0, double p1, double lp0, const UDiv &dlp, int np) {
-  const double log_pressure = log(0.5 * (p1 + p0));                      // :120
-  double pressure_index = udiv(log_pressure - lp0, dlp);
-  pressure_index = 1. + selmax(0., selmin(pressure_index, (double)np - 1.0001));
-  PPoint r;
+template <typename real> struct PPoint { int ip0; real pw0, pw1; };
+template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(real p0, real p1, real lp0, const UDivT<real> &dlp, int np) {
+  const real log_pressure = log(real(0.5) * (p1 + p0));                      // :120
+  real pressure_index = udiv(log_pressure - lp0, dlp);
+  pressure_index = real(1) + selmax(real(0), selmin(pressure_index, (real)np - real(1.0001)));
+  PPoint<real> r;
   r.ip0 = (int)pressure_index;
   r.pw1 = pressure_index - r.ip0;
-  r.pw0 = 1. - r.pw1;
+  r.pw0 = real(1) - r.pw1;
   return r;
 }
 
 // Planck interpolation point (:275-285).  Below the table the reference uses (T/t0)*B(:,1); that
 // is row 0 with weights (T/t0, 0): w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.
-struct PlPoint { int off; double w0, w1; };
-__device__ __forceinline__ PlPoint planck_point(double T, double t0, const UDiv &dt, int ntp, int SP) {
-  PlPoint p;
-  double temperature_index = udiv(T - t0, dt);
+template <typename real> struct PlPoint { int off; real w0, w1; };
+template <typename real> __device__ __forceinline__ PlPoint<real> planck_point(real Tk, real t0, const UDivT<real> &dt, int ntp, int SP) {
+  PlPoint<real> p;
+  real temperature_index = udiv(Tk - t0, dt);
   if (temperature_index >= 0) {
-    temperature_index = 1. + temperature_index;
-    const int it0 = temperature_index >= (double)(ntp - 1) ? ntp - 1 : (int)temperature_index;
+    temperature_index = real(1) + temperature_index;
+    const int it0 = temperature_index >= (real)(ntp - 1) ? ntp - 1 : (int)temperature_index;
     p.w1 = temperature_index - it0;
-    p.w0 = 1. - p.w1;
+    p.w0 = real(1) - p.w1;
     p.off = (it0 - 1) * SP;
   } else {
-    p.w0 = T / t0;
-    p.w1 = 0.;
+    p.w0 = Tk / t0;
+    p.w1 = real(0);
     p.off = 0;
   }
   return p;
 }
 
-__device__ __forceinline__ double div_pi(double x, double pi, double rpi) {
-  const double q = x * rpi;              // correctly rounded x/pi (Markstein), see kernels_planck.hip
-  const double r = fma(-q, pi, x);
+template <typename real> __device__ __forceinline__ real div_pi(real x, real pi, real rpi) {
+  const real q = x * rpi;              // correctly rounded x/pi (Markstein), see kernels_planck.hip
+  const real r = fma(-q, pi, x);
   return fma(r, rpi, q);
 }
 
@@ -129,6 +137,9 @@ __device__ __forceinline__ double swap_adjacent(double x) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float swap_adjacent(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
 
 // Stores the values of two consecutive g-points (planes o0, o1 of a column-fastest array) as ONE
 // 16-byte store per lane instead of two 8-byte ones: the lanes of an (even, odd) column pair
@@ -137,10 +148,11 @@ __device__ __forceinline__ double swap_adjacent(double x) {
 // dwordx4 (the kernel was store-issue bound).  Must be called by all lanes of the wave.
 //   c: column of this lane (even lanes hold even columns); o0, o1: element offsets of (column 0,
 //   plane) ; ok: this lane's column exists; pair_ok: both columns of the pair exist.
-__device__ __forceinline__ void store_pair(double *arr, long c, long o0, long o1, double v0, double v1,
+template <typename real>
+__device__ __forceinline__ void store_pair(real *arr, long c, long o0, long o1, real v0, real v1,
                                            bool odd, bool ok, bool pair_ok) {
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-  const double recv = swap_adjacent(odd ? v0 : v1);
+  typedef real double2_t __attribute__((ext_vector_type(2)));
+  const real recv = swap_adjacent(odd ? v0 : v1);
   if (pair_ok) {
     double2_t out;
     out[0] = odd ? recv : v0;
@@ -157,11 +169,12 @@ __device__ __forceinline__ void store_pair(double *arr, long c, long o0, long o1
   }
 }
 
-template <int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
 __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  real *lds = reinterpret_cast<real *>(lds_raw);
+  typedef real double2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const volatile real lds_cvd;
   typedef __attribute__((address_space(3))) const volatile double2_t lds_cvd2;
   lds_cvd *lv = (lds_cvd *)lds;
   // two consecutive g-points in one ds_read_b128 (x must be even)
@@ -174,17 +187,24 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   const int ntp = MODE == MODE_LW ? a.ntp : 0;
   const int ngp = (ng + GC - 1) / GC * GC;
   const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, ntp);
-  double *redd = lds + L.red;
+  real *redd = lds + L.red;
+  // The argument structs carry `double` pointers and scalars; in the single-precision
+  // instantiation the pointers address float data (host side casts) and the scalars are rounded.
+  auto P = [](const double *p) { return reinterpret_cast<const real *>(p); };
+  auto Q = [](double *p) { return reinterpret_cast<real *>(p); };
+  const UDivT<real> ud_dlp = make_udiv_t<real>(a.ud_dlp), ud_dt = make_udiv_t<real>(a.ud_dt);
+  const UDivT<real> ud_dlv = make_udiv_t<real>(a.ud_dlv), ud_pdt = make_udiv_t<real>(a.ud_pdt);
+  const real lp0 = (real)t.lp0, gw = (real)t.gw, pt0 = (real)a.pt0;
 
   // Everything a zero-weight slot (unused bilinear slot, absent look_up_table gas) can read must
   // be finite: clear the whole allocation once, the staged rows overwrite their part.
-  for (int i = tid; i < L.total; i += kBlock) lds[i] = 0.;
+  for (int i = tid; i < L.total; i += kBlock) lds[i] = real(0);
   __syncthreads();
-  for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = t.temperature[i];
+  for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = P(t.temperature)[i];
   if (MODE == MODE_LW) {
     for (int q = tid; q < ntp * ng; q += kBlock) {
       const int r = q / ng, g = q - r * ng;
-      lds[L.pl + r * L.SP + g] = a.planck[q];
+      lds[L.pl + r * L.SP + g] = P(a.planck)[q];
     }
   }
 
@@ -192,17 +212,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   const long t_begin = ntiles * blockIdx.x / gridDim.x;
   const long t_end = ntiles * (blockIdx.x + 1) / gridDim.x;
   int slab_lo = -1;
-  const double *plev0 = t.plev + (long)ncol * j, *plev1 = t.plev + (long)ncol * (j + 1);
-  const double pi = (double)3.14159265359f, rpi = 1. / pi;   // :53
+  const real *plev0 = P(t.plev) + (long)ncol * j, *plev1 = P(t.plev) + (long)ncol * (j + 1);
+  const real pi = (real)3.14159265359f, rpi = real(1) / pi;   // :53
 
   for (long seg = t_begin; seg < t_end; seg += kSeg) {
     const long seg_end = seg + kSeg < t_end ? seg + kSeg : t_end;
     // ---- pre-pass: range of p0+p1 over the segment; the pressure index is monotone in it ----
-    double smin = 1.0e300, smax = -1.0e300;
+    real smin = real(3.0e38), smax = -real(3.0e38);
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
       if (c < ncol) {
-        const double sp = plev1[c] + plev0[c];
+        const real sp = plev1[c] + plev0[c];
         smin = selmin(smin, sp);
         smax = selmax(smax, sp);
       }
@@ -221,8 +241,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     int ipmin = 1, ipmax = 0;
     if (smin <= smax) {
       // same expression as pressure_point(): log(0.5*(p1+p0)); 0 + s == s exactly
-      ipmin = pressure_point(0., smin, t.lp0, a.ud_dlp, np).ip0;
-      ipmax = pressure_point(0., smax, t.lp0, a.ud_dlp, np).ip0;
+      ipmin = pressure_point<real>(real(0), smin, lp0, ud_dlp, np).ip0;
+      ipmax = pressure_point<real>(real(0), smax, lp0, ud_dlp, np).ip0;
     }
     if (R >= 2 && ipmin <= ipmax && !(slab_lo >= 0 && ipmin - 1 >= slab_lo && ipmax <= slab_lo + R - 1)) {
       slab_lo = min(ipmin - 1, np - R);
@@ -231,17 +251,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       for (int q = wave; q < items_b; q += kWaves) {
         const int s = q % t.nbil, rb = q / t.nbil;
         const int ipl = rb % R, it = rb / R;
-        const double *src = t.seq[t.bil_seq[s]].coef + (long)ng * ((slab_lo + ipl) + (long)np * it);
-        double *dst = lds + L.bil + rb * L.SB + s * ngp;
+        const real *src = P(t.seq[t.bil_seq[s]].coef) + (long)ng * ((slab_lo + ipl) + (long)np * it);
+        real *dst = lds + L.bil + rb * L.SB + s * ngp;
         for (int g = lane; g < ng; g += 64) dst[g] = src[g];
       }
       if (t.lut >= 0) {
-        const double *coef = t.seq[t.lut].coef;
+        const real *coef = P(t.seq[t.lut].coef);
         const int rows_l = rows_b * nv_lut;
         for (int q = wave; q < rows_l; q += kWaves) {
           const int ipl = q % R, itv = q / R;
-          const double *src = coef + (long)ng * ((slab_lo + ipl) + (long)np * itv);
-          double *dst = lds + L.lut + q * L.SL;
+          const real *src = coef + (long)ng * ((slab_lo + ipl) + (long)np * itv);
+          real *dst = lds + L.lut + q * L.SL;
           for (int g = lane; g < ng; g += 64) dst[g] = src[g];
         }
       }
@@ -255,48 +275,48 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const bool pair_ok = ((c | 1) < ncol) && !t.debug_nostore;   // both columns of this lane pair exist
       const long cc = c < ncol ? c : (long)ncol - 1;
       // ---- setup: one round of global loads ----
-      const double p0 = plev0[cc], p1 = plev1[cc];
-      const double T = t.tlay[cc + (long)ncol * j];
-      double W[NB];        // per-slot vmr, then weight (:143-149); 0 for unused slots
+      const real p0 = plev0[cc], p1 = plev1[cc];
+      const real Tlayer = P(t.tlay)[cc + (long)ncol * j];
+      real W[NB];        // per-slot vmr, then weight (:143-149); 0 for unused slots
 #pragma unroll
-      for (int s = 0; s < NB; ++s) W[s] = a.slot[s].vmr[cc * a.slot[s].cs + j * a.slot[s].ls];
-      double vlut = a.slot[kTauPassGases].vmr[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
-      double Tl0 = 0., Tl1 = 0.;
+      for (int s = 0; s < NB; ++s) W[s] = P(a.slot[s].vmr)[cc * a.slot[s].cs + j * a.slot[s].ls];
+      real vlut = P(a.slot[kTauPassGases].vmr)[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
+      real Tl0 = real(0), Tl1 = real(0);
       if (MODE == MODE_LW && a.tlev) {
-        Tl0 = a.tlev[cc + (long)ncol * j];
-        Tl1 = a.tlev[cc + (long)ncol * (j + 1)];
+        Tl0 = P(a.tlev)[cc + (long)ncol * j];
+        Tl1 = P(a.tlev)[cc + (long)ncol * (j + 1)];
       }
 
-      const PPoint pp = pressure_point(p0, p1, t.lp0, a.ud_dlp, np);
+      const PPoint<real> pp = pressure_point<real>(p0, p1, lp0, ud_dlp, np);
       const int ip0 = pp.ip0;
       const int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
       const bool fast = __all(inslab);
 
-      const double t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
-      double temperature_index = udiv(T - t0, a.ud_dt);
-      temperature_index = 1. + selmax(0., selmin(temperature_index, (double)nt - 1.0001));
+      const real t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
+      real temperature_index = udiv(Tlayer - t0, ud_dt);
+      temperature_index = real(1) + selmax(real(0), selmin(temperature_index, (real)nt - real(1.0001)));
       const int it0 = (int)temperature_index;
-      const double tw1 = temperature_index - it0;
-      const double tw0 = 1. - tw1;
-      const double dp = p1 - p0;
-      const double simple_weight = t.gw * dp;   // :143
+      const real tw1 = temperature_index - it0;
+      const real tw0 = real(1) - tw1;
+      const real dp = p1 - p0;
+      const real simple_weight = gw * dp;   // :143
 
       // corner weights, multiplied out once per cell
-      const double a00 = tw0 * pp.pw0, a10 = tw0 * pp.pw1, a01 = tw1 * pp.pw0, a11 = tw1 * pp.pw1;
-      double l000 = 0., l100 = 0., l010 = 0., l110 = 0., l001 = 0., l101 = 0., l011 = 0., l111 = 0.;
+      const real a00 = tw0 * pp.pw0, a10 = tw0 * pp.pw1, a01 = tw1 * pp.pw0, a11 = tw1 * pp.pw1;
+      real l000 = real(0), l100 = real(0), l010 = real(0), l110 = real(0), l001 = real(0), l101 = real(0), l011 = real(0), l111 = real(0);
       int iv0 = 1;
       if (t.lut >= 0) {   // :153-163
         const SeqGas &e = t.seq[t.lut];
-        vlut = a.slot[kTauPassGases].use_scalar ? a.slot[kTauPassGases].scalar : vlut;
-        const double log_vmr = log(selmax(vlut, e.mf0));
-        double vmr_index = udiv(log_vmr - e.log_mf0, a.ud_dlv);
-        vmr_index = 1. + selmax(0., selmin(vmr_index, (double)e.nv - 1.001));
+        vlut = a.slot[kTauPassGases].use_scalar ? (real)a.slot[kTauPassGases].scalar : vlut;
+        const real log_vmr = log(selmax(vlut, (real)e.mf0));
+        real vmr_index = udiv(log_vmr - (real)e.log_mf0, ud_dlv);
+        vmr_index = real(1) + selmax(real(0), selmin(vmr_index, (real)e.nv - real(1.001)));
         iv0 = (int)vmr_index;
-        const double vw1 = vmr_index - iv0, vw0 = 1. - vw1;
-        double wl = simple_weight * vlut;   // :148
-        if (!ANYCLAMP) wl = wl < 0. ? 0. : wl;
-        const double u0 = ANYCLAMP ? vw0 : wl * vw0, u1 = ANYCLAMP ? vw1 : wl * vw1;
+        const real vw1 = vmr_index - iv0, vw0 = real(1) - vw1;
+        real wl = simple_weight * vlut;   // :148
+        if (!ANYCLAMP) wl = wl < real(0) ? real(0) : wl;
+        const real u0 = ANYCLAMP ? vw0 : wl * vw0, u1 = ANYCLAMP ? vw1 : wl * vw1;
         l000 = u0 * a00; l100 = u0 * a10; l010 = u0 * a01; l110 = u0 * a11;
         l001 = u1 * a00; l101 = u1 * a10; l011 = u1 * a01; l111 = u1 * a11;
         if (ANYCLAMP) vlut = wl;   // keep the weight; applied (and clamped) per g-point
@@ -304,18 +324,18 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
       for (int s = 0; s < NB; ++s) {
         const SlotArgs &e = a.slot[s];
-        const double v = e.use_scalar ? e.scalar : W[s];
-        double x = e.code == 3 ? simple_weight * (v - e.ref) : (e.code == 0 ? simple_weight : simple_weight * v);
-        if (!ANYCLAMP) x = x < 0. ? 0. : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
-        W[s] = s < t.nbil ? x : 0.;
+        const real v = e.use_scalar ? (real)e.scalar : W[s];
+        real x = e.code == 3 ? simple_weight * (v - (real)e.ref) : (e.code == 0 ? simple_weight : simple_weight * v);
+        if (!ANYCLAMP) x = x < real(0) ? real(0) : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
+        W[s] = s < t.nbil ? x : real(0);
       }
-      PlPoint qlay{0, 0., 0.}, ql0{0, 0., 0.}, ql1{0, 0., 0.};
+      PlPoint<real> qlay{0, real(0), real(0)}, ql0{0, real(0), real(0)}, ql1{0, real(0), real(0)};
       if (MODE == MODE_LW) {
-        qlay = planck_point(T, a.pt0, a.ud_pdt, ntp, L.SP);
-        ql0 = planck_point(Tl0, a.pt0, a.ud_pdt, ntp, L.SP);
-        ql1 = planck_point(Tl1, a.pt0, a.ud_pdt, ntp, L.SP);
+        qlay = planck_point<real>(Tlayer, pt0, ud_pdt, ntp, L.SP);
+        ql0 = planck_point<real>(Tl0, pt0, ud_pdt, ntp, L.SP);
+        ql1 = planck_point<real>(Tl1, pt0, ud_pdt, ntp, L.SP);
       }
-      const double moles = dp * t.gw;   // :313-314 (SW)
+      const real moles = dp * gw;   // :313-314 (SW)
 
       if (fast) {
         // The g-point work of a chunk is a static sequence of "items" -- one g-point of the
@@ -332,14 +352,14 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         const int dPb = L.SB, dTb = R * L.SB;
         const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
         for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
-          double acc[GC];
+          real acc[GC];
           if (t.accumulate) {
 #pragma unroll
             for (int g = 0; g < GC; ++g)
-              acc[g] = (FULL || gb + g < ng) ? t.tau[cc + (long)ncol * (j + (long)nlay * (gb + g))] : 0.;
+              acc[g] = (FULL || gb + g < ng) ? P(t.tau)[cc + (long)ncol * (j + (long)nlay * (gb + g))] : real(0);
           } else {
 #pragma unroll
-            for (int g = 0; g < GC; ++g) acc[g] = 0.;
+            for (int g = 0; g < GC; ++g) acc[g] = real(0);
           }
           const int pb = L.pl + gb;
           double2_t buf[2][8];
@@ -374,11 +394,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                   const int g = 2 * pi_ + q;
-                  double v = l000 * b[0][q];
+                  real v = l000 * b[0][q];
                   v = fma(l100, b[1][q], v); v = fma(l010, b[2][q], v); v = fma(l110, b[3][q], v);
                   v = fma(l001, b[4][q], v); v = fma(l101, b[5][q], v); v = fma(l011, b[6][q], v);
                   v = fma(l111, b[7][q], v);
-                  if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
+                  if (ANYCLAMP) { v = vlut * v; v = v < real(0) ? real(0) : v; }
                   acc[g] = acc[g] + v;
                   asm volatile("" : "+v"(acc[g]));
                 }
@@ -387,9 +407,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int h = (q >> 1) * 4, e = q & 1;
-                  double v = a00 * b[h][e];
+                  real v = a00 * b[h][e];
                   v = fma(a10, b[h + 1][e], v); v = fma(a01, b[h + 2][e], v); v = fma(a11, b[h + 3][e], v);
-                  if (ANYCLAMP) { v = W[s] * v; v = v < 0. ? 0. : v; acc[g0 + q] = acc[g0 + q] + v; }
+                  if (ANYCLAMP) { v = W[s] * v; v = v < real(0) ? real(0) : v; acc[g0 + q] = acc[g0 + q] + v; }
                   else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
                   asm volatile("" : "+v"(acc[g0 + q]));
                 }
@@ -399,32 +419,32 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                     if (FULL || gb + g + 1 < ng) {
                       const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
                       if (MODE == MODE_SW) {
-                        const double r0 = moles * t.rayleigh[gb + g], r1 = moles * t.rayleigh[gb + g + 1];   // :316
-                        const double t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair(t.tau, c, o0, o1, t0_, t1_, odd, valid, pair_ok);
+                        const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
+                        const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
+                        store_pair<real>(Q(t.tau), c, o0, o1, t0_, t1_, odd, valid, pair_ok);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair(t.ssa, c, o0, o1, r0 / t0_, r1 / t1_, odd, valid, pair_ok);
-                          store_pair(t.g, c, o0, o1, 0., 0., odd, valid, pair_ok);
+                          store_pair<real>(Q(t.ssa), c, o0, o1, r0 / t0_, r1 / t1_, odd, valid, pair_ok);
+                          store_pair<real>(Q(t.g), c, o0, o1, real(0), real(0), odd, valid, pair_ok);
                         }
                       } else {
-                        store_pair(t.tau, c, o0, o1, acc[g], acc[g + 1], odd, valid, pair_ok);
+                        store_pair<real>(Q(t.tau), c, o0, o1, acc[g], acc[g + 1], odd, valid, pair_ok);
                       }
                     } else if (gb + g < ng && valid) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
                       if (MODE == MODE_SW) {
-                        const double ray = moles * t.rayleigh[gb + g];
-                        const double tt = acc[g] + ray;
-                        t.tau[o] = tt;
-                        if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }
+                        const real ray = moles * P(t.rayleigh)[gb + g];
+                        const real tt = acc[g] + ray;
+                        Q(t.tau)[o] = tt;
+                        if (t.ssa) { Q(t.ssa)[o] = ray / tt; Q(t.g)[o] = real(0); }
                       } else {
-                        t.tau[o] = acc[g];
+                        Q(t.tau)[o] = acc[g];
                       }
                     }
                   }
                 }
               } else {
                 const int g = 2 * (pi_ - NLI - NBI);
-                double vl[2], v0[2], v1[2];
+                real vl[2], v0[2], v1[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                   vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
@@ -433,15 +453,15 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                 }
                 if (FULL || gb + g + 1 < ng) {
                   const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
-                  store_pair(a.lay_source, c, o0, o1, vl[0], vl[1], odd, valid, pair_ok);
+                  store_pair<real>(Q(a.lay_source), c, o0, o1, vl[0], vl[1], odd, valid, pair_ok);
                   if (a.tlev) {                                                      // :423-424
-                    store_pair(a.lev_source_dec, c, o0, o1, v0[0], v0[1], odd, valid, pair_ok);
-                    store_pair(a.lev_source_inc, c, o0, o1, v1[0], v1[1], odd, valid, pair_ok);
+                    store_pair<real>(Q(a.lev_source_dec), c, o0, o1, v0[0], v0[1], odd, valid, pair_ok);
+                    store_pair<real>(Q(a.lev_source_inc), c, o0, o1, v1[0], v1[1], odd, valid, pair_ok);
                   }
                 } else if (gb + g < ng && valid) {
                   const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
-                  a.lay_source[o] = vl[0];
-                  if (a.tlev) { a.lev_source_dec[o] = v0[0]; a.lev_source_inc[o] = v1[0]; }
+                  Q(a.lay_source)[o] = vl[0];
+                  if (a.tlev) { Q(a.lev_source_dec)[o] = v0[0]; Q(a.lev_source_inc)[o] = v1[0]; }
                 }
               }
             }
@@ -451,12 +471,12 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         // ---- a lane of this wave is outside the staged rows: tables from global memory ----
         for (int g = 0; g < ng; ++g) {
           const long o = cc + (long)ncol * (j + (long)nlay * g);
-          double acc = t.accumulate ? t.tau[o] : 0.;
+          real acc = t.accumulate ? P(t.tau)[o] : real(0);
           if (t.lut >= 0) {
             const SeqGas &e = t.seq[t.lut];
-            const double *cp = e.coef + (long)ng * ((ip0 - 1) + (long)np * ((it0 - 1) + (long)nt * (iv0 - 1))) + g;
+            const real *cp = P(e.coef) + (long)ng * ((ip0 - 1) + (long)np * ((it0 - 1) + (long)nt * (iv0 - 1))) + g;
             const long dP = ng, dT = (long)ng * np, dV = (long)ng * np * nt;
-            double v = l000 * cp[0];
+            real v = l000 * cp[0];
             v = fma(l100, cp[dP], v);
             v = fma(l010, cp[dT], v);
             v = fma(l110, cp[dT + dP], v);
@@ -464,37 +484,37 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
             v = fma(l101, cp[dV + dP], v);
             v = fma(l011, cp[dV + dT], v);
             v = fma(l111, cp[dV + dT + dP], v);
-            if (ANYCLAMP) { v = vlut * v; v = v < 0. ? 0. : v; }
+            if (ANYCLAMP) { v = vlut * v; v = v < real(0) ? real(0) : v; }
             acc = acc + v;
           }
 #pragma unroll
           for (int s = 0; s < NB; ++s) {
             if (s < t.nbil) {
-              const double *cp = t.seq[t.bil_seq[s]].coef + (long)ng * ((ip0 - 1) + (long)np * (it0 - 1)) + g;
+              const real *cp = P(t.seq[t.bil_seq[s]].coef) + (long)ng * ((ip0 - 1) + (long)np * (it0 - 1)) + g;
               const long dP = ng, dT = (long)ng * np;
-              double v = a00 * cp[0];
+              real v = a00 * cp[0];
               v = fma(a10, cp[dP], v);
               v = fma(a01, cp[dT], v);
               v = fma(a11, cp[dT + dP], v);
-              if (ANYCLAMP) { v = W[s] * v; v = v < 0. ? 0. : v; acc = acc + v; }
+              if (ANYCLAMP) { v = W[s] * v; v = v < real(0) ? real(0) : v; acc = acc + v; }
               else acc = fma(W[s], v, acc);
             }
           }
           if (valid) {
             if (MODE == MODE_SW) {
-              const double ray = moles * t.rayleigh[g];
-              const double tt = acc + ray;
-              t.tau[o] = tt;
-              if (t.ssa) { t.ssa[o] = ray / tt; t.g[o] = 0.; }
+              const real ray = moles * P(t.rayleigh)[g];
+              const real tt = acc + ray;
+              Q(t.tau)[o] = tt;
+              if (t.ssa) { Q(t.ssa)[o] = ray / tt; Q(t.g)[o] = real(0); }
             } else {
-              t.tau[o] = acc;
+              Q(t.tau)[o] = acc;
             }
             if (MODE == MODE_LW) {
               const int pb = L.pl + g;
-              a.lay_source[o] = div_pi(qlay.w0 * lv[pb + qlay.off] + qlay.w1 * lv[pb + qlay.off + L.SP], pi, rpi);
+              Q(a.lay_source)[o] = div_pi(qlay.w0 * lv[pb + qlay.off] + qlay.w1 * lv[pb + qlay.off + L.SP], pi, rpi);
               if (a.tlev) {
-                a.lev_source_dec[o] = div_pi(ql0.w0 * lv[pb + ql0.off] + ql0.w1 * lv[pb + ql0.off + L.SP], pi, rpi);
-                a.lev_source_inc[o] = div_pi(ql1.w0 * lv[pb + ql1.off] + ql1.w1 * lv[pb + ql1.off + L.SP], pi, rpi);
+                Q(a.lev_source_dec)[o] = div_pi(ql0.w0 * lv[pb + ql0.off] + ql0.w1 * lv[pb + ql0.off + L.SP], pi, rpi);
+                Q(a.lev_source_inc)[o] = div_pi(ql1.w0 * lv[pb + ql1.off] + ql1.w1 * lv[pb + ql1.off + L.SP], pi, rpi);
               }
             }
           }
@@ -503,18 +523,18 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       // ---- surface source (:408-413), by the blocks of the first layer ----
       if (MODE == MODE_LW && j == 0 && valid) {
-        const PlPoint qs = planck_point(a.tsfc[c], a.pt0, a.ud_pdt, ntp, L.SP);
+        const PlPoint<real> qs = planck_point<real>(P(a.tsfc)[c], pt0, ud_pdt, ntp, L.SP);
         for (int g = 0; g < ng; ++g)
-          a.sfc_source[c + (long)ncol * g] =
+          Q(a.sfc_source)[c + (long)ncol * g] =
               div_pi(qs.w0 * lv[L.pl + qs.off + g] + qs.w1 * lv[L.pl + qs.off + L.SP + g], pi, rpi);
       }
     }
   }
 }
 
-template <int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
 hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
-  auto k = gas_fused_kernel<GC, NB, FULL, ANYCLAMP, MODE>;
+  auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -531,14 +551,14 @@ int pick_nb(int nbil) {
   return kTauPassGases;
 }
 
-template <int MODE>
+template <typename real, int MODE>
 hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp, hipStream_t s) {
   const int ng = a.tau.ng;
-  if (anyclamp) return launch_one<4, kTauPassGases, false, true, MODE>(a, lds, s);
-  if (NBsel == 7 && ng % 8 == 0) return launch_one<8, 7, true, false, MODE>(a, lds, s);
-  if (NBsel == 7 && ng % 4 == 0) return launch_one<4, 7, true, false, MODE>(a, lds, s);
-  if (NBsel == 5) return launch_one<4, 5, false, false, MODE>(a, lds, s);
-  return launch_one<4, kTauPassGases, false, false, MODE>(a, lds, s);
+  if (anyclamp) return launch_one<real, 4, kTauPassGases, false, true, MODE>(a, lds, s);
+  if (NBsel == 7 && ng % 8 == 0) return launch_one<real, 8, 7, true, false, MODE>(a, lds, s);
+  if (NBsel == 7 && ng % 4 == 0) return launch_one<real, 4, 7, true, false, MODE>(a, lds, s);
+  if (NBsel == 5) return launch_one<real, 4, 5, false, false, MODE>(a, lds, s);
+  return launch_one<real, 4, kTauPassGases, false, false, MODE>(a, lds, s);
 }
 
 // (GC, NB) of the instantiation launch_mode() will pick
@@ -554,36 +574,44 @@ void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
 }  // namespace
 
 // Rows of the LDS slab for a fused launch, or 0 if it does not fit with at least `min_rows`.
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp) {
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp, int f32) {
   int GC, NB;
   pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
   const int ngp = (ng + GC - 1) / GC * GC;
+  const size_t esz = f32 ? sizeof(float) : sizeof(double);
   int R = 0;
   for (int r = 2; r <= np; ++r) {
-    if (sizeof(double) * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
+    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
     else break;
   }
   return R >= min_rows ? R : 0;
 }
 
-UDiv make_udiv(double d) {
+UDiv make_udiv(double d, int f32) {
   UDiv u;
+  if (f32) d = (double)(float)d;   // the kernel works with the rounded divisor
   u.d = d;
   u.r = 1. / d;
   unsigned long long bits;
   static_assert(sizeof(bits) == sizeof(d), "");
   __builtin_memcpy(&bits, &d, 8);
-  const bool all_ones = (bits & 0xFFFFFFFFFFFFFULL) == 0xFFFFFFFFFFFFFULL;
+  bool all_ones = (bits & 0xFFFFFFFFFFFFFULL) == 0xFFFFFFFFFFFFFULL;
+  if (f32) {
+    const float df = (float)d;
+    unsigned int b32;
+    __builtin_memcpy(&b32, &df, 4);
+    all_ones = (b32 & 0x7FFFFFu) == 0x7FFFFFu;
+  }
   u.exact = (d == d) && d != 0. && (d - d == 0.) && !all_ones && (u.r - u.r == 0.) ? 1 : 0;
   return u;
 }
 
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   TauArgs &t = a.tau;
-  a.ud_dlp = make_udiv(t.dlp);
-  a.ud_dt = make_udiv(t.dt);
-  a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1.);
-  a.ud_pdt = make_udiv(a.mode == MODE_LW ? a.pdt : 1.);
+  a.ud_dlp = make_udiv(t.dlp, a.f32);
+  a.ud_dt = make_udiv(t.dt, a.f32);
+  a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1., a.f32);
+  a.ud_pdt = make_udiv(a.mode == MODE_LW ? a.pdt : 1., a.f32);
   for (int s = 0; s <= kTauPassGases; ++s) {
     const int k = s < kTauPassGases ? (s < t.nbil ? t.bil_seq[s] : -1) : t.lut;
     SlotArgs &o = a.slot[s];
@@ -607,8 +635,8 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   int GC, NB;
   pick_shape(t.ng, t.nbil, anyclamp, &GC, &NB);
   const int ngp = (t.ng + GC - 1) / GC * GC;
-  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0, anyclamp);
-  const size_t lds = sizeof(double) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0, anyclamp, a.f32);
+  const size_t lds = (a.f32 ? sizeof(float) : sizeof(double)) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full
@@ -619,9 +647,13 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   if (chunks * kSeg > ntiles) chunks = (ntiles + kSeg - 1) / kSeg;
   if (chunks < 1) chunks = 1;
   t.col_chunks = (int)chunks;
-  if (a.mode == MODE_LW) return launch_mode<MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
-  if (a.mode == MODE_SW) return launch_mode<MODE_SW>(a, lds, pick_nb(t.nbil), anyclamp, s);
-  return launch_mode<MODE_TAU>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  if (a.f32) {   // single precision: the longwave fused path only
+    if (a.mode != MODE_LW) return hipErrorNotSupported;
+    return launch_mode<float, MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  }
+  if (a.mode == MODE_LW) return launch_mode<double, MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  if (a.mode == MODE_SW) return launch_mode<double, MODE_SW>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  return launch_mode<double, MODE_TAU>(a, lds, pick_nb(t.nbil), anyclamp, s);
 }
 
 }  // namespace ecckd

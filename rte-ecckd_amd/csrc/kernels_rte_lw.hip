@@ -34,42 +34,59 @@ namespace {
 #ifndef ECCKD_LW_CW
 #define ECCKD_LW_CW 32
 #endif
+#ifndef ECCKD_LW_CW_F32
+#define ECCKD_LW_CW_F32 32
+#endif
 constexpr int kPF = ECCKD_LW_PF;   // prefetch depth in layers
 constexpr int kSchedSpan = 2;   // layers the instruction scheduler may interleave
 
-template <int CW>
-__device__ __forceinline__ double gsum(double v) {
+template <typename real, int CW>
+__device__ __forceinline__ real gsum(real v) {
   // sum over the lanes that share a column: lane = cl + CW*gs
 #pragma unroll
   for (int o = CW; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
   return v;
 }
 
-// acc += v by the owner lane (gs == 0) only.  The other lanes add +0.0 to the same word, which
-// leaves the sum bit-identical whatever order the LDS unit serialises them in; one fire-and-
-// forget ds_add_f64 replaces an exec-masked read/wait/add/write that would expose the full LDS
-// latency twice per layer at one wave per SIMD.
-__device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
-  __hip_atomic_fetch_add(p, owner ? v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+// acc += v by the owner lane (gs == 0) only, as one fire-and-forget ds_add_f64 (an exec-masked
+// read/wait/add/write would expose the full LDS latency twice per layer at one wave per SIMD).
+// The accumulators are double in both precisions: ds_add_f32 retires one lane every 3 clocks on
+// gfx950 (193 clocks per wave instruction, tools/ubench_atomic.hip) against 6-13 clocks for
+// ds_add_f64, and the broadband sum is the better for it.
+// Every lane issues the atomic and non-owners add +0.0, which leaves the sum bit-identical whatever
+// order the LDS unit serialises them in.  Exec-masking the owners (ECCKD_LW_MASKED) makes the
+// atomic itself cheaper (10.0 against 12.9 clocks at 4 waves per CU) but the exec juggling costs
+// more than that in the kernel: measured 2-5 % slower.
+template <typename real>
+__device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
+#ifdef ECCKD_LW_MASKED
+  if (owner) __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+  __hip_atomic_fetch_add(p, owner ? (double)v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 }
 
-template <int NL, int CW>
+template <typename real, int NL, int CW>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   constexpr int GW = 64 / CW;
-  extern __shared__ double acc[];   // [2][nlay+1][CW]
+  extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
+  double *acc = reinterpret_cast<double *>(acc_raw);   // [2][nlay+1][CW], double in both precisions
+  // RteLwArgs carries `double` pointers; in the single-precision instantiation they address float data
+  auto P = [](const double *p) { return reinterpret_cast<const real *>(p); };
+  auto Q = [](double *p) { return reinterpret_cast<real *>(p); };
   const int lane = threadIdx.x;
   const int cl = lane % CW, gs = lane / CW;
   const bool owner = gs == 0;
   const int ncol = a.ncol, nlay = a.nlay, ng = a.ng;
   const int nlev = nlay + 1;
   double *acc_dn = acc, *acc_up = acc + nlev * CW;
-  const double pi = acos(-1.);
-  const double tau_thresh = 1.4901161193847656e-08;   // sqrt(epsilon(1._wp))
+  const real pi = (real)acos(-1.);
+  const real tau_thresh = sizeof(real) == 8 ? (real)1.4901161193847656e-08 : (real)3.4526698300124393e-04;   // sqrt(epsilon(1._wp))
   // layer / level walked s-th from the top lives at index l0 + s*lstep
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
   const long lstep = a.top_at_1 ? 1 : -1;
-  const double *Bdn = a.top_at_1 ? a.lev_source_inc : a.lev_source_dec;
-  const double *Bup = a.top_at_1 ? a.lev_source_dec : a.lev_source_inc;
+  const real *Bdn = P(a.top_at_1 ? a.lev_source_inc : a.lev_source_dec);
+  const real *Bup = P(a.top_at_1 ? a.lev_source_dec : a.lev_source_inc);
   const int ngroups = (ng + GW - 1) / GW;
   const int niter = ngroups * a.nmus;
   const long ntiles = ((long)ncol + CW - 1) / CW;
@@ -80,13 +97,13 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     const long cc = valid ? col : (long)ncol - 1;
     for (int i = lane; i < 2 * nlev * CW; i += 64) acc[i] = 0.;
 
-    [[maybe_unused]] double T[NL > 0 ? NL : 1], SU[NL > 0 ? NL : 1];
-    [[maybe_unused]] double *sT = nullptr, *sSU = nullptr;
+    [[maybe_unused]] real T[NL > 0 ? NL : 1], SU[NL > 0 ? NL : 1];
+    [[maybe_unused]] real *sT = nullptr, *sSU = nullptr;
     if constexpr (NL == 0) {
-      sT = a.scratch + ((long)blockIdx.x * 2 * nlay) * 64 + lane;
+      sT = Q(a.scratch) + ((long)blockIdx.x * 2 * nlay) * 64 + lane;
       sSU = sT + (long)nlay * 64;
     }
-    double ptau[kPF], play[kPF], pbdn[kPF], pbup[kPF];
+    real ptau[kPF], play[kPF], pbdn[kPF], pbup[kPF];
 
     // Element offset of the next layer to prefetch.  It is advanced step by step and made
     // opaque to the optimiser after every advance: otherwise the fully unrolled layer loop is
@@ -101,13 +118,13 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     };
     auto issue = [&](int slot) {
 #ifndef ECCKD_LW_PLAIN_LOADS   // nontemporal: read-once streams
-      ptau[slot] = __builtin_nontemporal_load(a.tau + qn);
-      play[slot] = __builtin_nontemporal_load(a.lay_source + qn);
+      ptau[slot] = __builtin_nontemporal_load(P(a.tau) + qn);
+      play[slot] = __builtin_nontemporal_load(P(a.lay_source) + qn);
       pbdn[slot] = __builtin_nontemporal_load(Bdn + qn);
       pbup[slot] = __builtin_nontemporal_load(Bup + qn);
 #else
-      ptau[slot] = a.tau[qn];
-      play[slot] = a.lay_source[qn];
+      ptau[slot] = P(a.tau)[qn];
+      play[slot] = P(a.lay_source)[qn];
       pbdn[slot] = Bdn[qn];
       pbup[slot] = Bup[qn];
 #endif
@@ -117,7 +134,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     // Same, but pinned into the recurrence: the empty asm also "modifies" the running
     // intensity, so the loads for layer s+kPF cannot be hoisted above layer s-1 (without this
     // the scheduler issues dozens of layers of loads up front and spills the register file).
-    auto issue_after = [&](int slot, double &pin) {
+    auto issue_after = [&](int slot, real &pin) {
       asm volatile("" : "+v"(qn), "+v"(pin));
       issue(slot);
     };
@@ -134,37 +151,37 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       const bool gact = g < ng;
       const int gg = gact ? g : ng - 1;
       const long base = cc + (long)ncol * nlay * gg;
-      const double D = a.Ds[k];
-      const double wfac = gact ? 2. * pi * a.wts[k] : 0.;
-      const double eps = a.sfc_emis[a.gpt2band[gg] + (long)a.nband * cc];
-      const double sfc_src = a.sfc_source[cc + (long)ncol * gg];
+      const real D = (real)a.Ds[k];
+      const real wfac = gact ? real(2) * pi * (real)a.wts[k] : real(0);
+      const real eps = P(a.sfc_emis)[a.gpt2band[gg] + (long)a.nband * cc];
+      const real sfc_src = P(a.sfc_source)[cc + (long)ncol * gg];
 
       // ---------------- down sweep ----------------
-      double I = 0.;   // no incident diffuse flux: radn_dn(top) = 0
-      auto layer = [&](int s, double tau, double lay, double bdn, double bup, double &t_out,
-                       double &su_out) {
-        const double tl = tau * D;
-        const double t = exp(-tl);
-        const double omt = 1. - t;
+      real I = real(0);   // no incident diffuse flux: radn_dn(top) = 0
+      auto layer = [&](int s, real tau, real lay, real bdn, real bup, real &t_out,
+                       real &su_out) {
+        const real tl = tau * D;
+        const real t = exp(-tl);
+        const real omt = real(1) - t;
         // both branches of lw_source_noscat's merge() are evaluated and selected (no branch)
-        const double fact_big = omt / tl - t;
-        const double fact_small = tl * (0.5 - 1. / 3. * tl);
-        const double fact = tl > tau_thresh ? fact_big : fact_small;
-        const double sdn = omt * bdn + 2. * fact * (lay - bdn);
-        double su = omt * bup + 2. * fact * (lay - bup);
+        const real fact_big = omt / tl - t;
+        const real fact_small = tl * (real(0.5) - real(1) / real(3) * tl);
+        const real fact = tl > tau_thresh ? fact_big : fact_small;
+        const real sdn = omt * bdn + real(2) * fact * (lay - bdn);
+        real su = omt * bup + real(2) * fact * (lay - bup);
         // Materialise source_up here: left alone, the optimiser sinks this expression into the
         // up sweep and keeps its five inputs alive per layer instead of the one result.
         asm volatile("" : "+v"(su));
         su_out = su;
         t_out = t;
-        const double v = gsum<CW>(wfac * I);
+        const real v = gsum<real, CW>(wfac * I);
         acc_add(&acc_dn[s * CW + cl], v, owner);
         I = t * I + sdn;
       };
       if constexpr (NL > 0) {
 #pragma unroll
         for (int s = 0; s < NL; ++s) {
-          const double tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF],
+          const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF],
                        bup = pbup[s % kPF];
           if (s + kPF < NL) issue_after(s % kPF, I);
           layer(s, tau, lay, bdn, bup, T[s], SU[s]);
@@ -179,20 +196,20 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       } else {
         for (int s = 0; s < nlay; ++s) {
           const long q = base + (long)ncol * (lay0 + lstep * s);
-          double t, su;
-          layer(s, a.tau[q], a.lay_source[q], Bdn[q], Bup[q], t, su);
+          real t, su;
+          layer(s, P(a.tau)[q], P(a.lay_source)[q], Bdn[q], Bup[q], t, su);
           sT[(long)s * 64] = t;
           sSU[(long)s * 64] = su;
         }
       }
       {
-        const double v = gsum<CW>(wfac * I);
+        const real v = gsum<real, CW>(wfac * I);
         acc_add(&acc_dn[nlay * CW + cl], v, owner);
       }
       // ---------------- surface + up sweep ----------------
-      double U = I * (1. - eps) + eps * sfc_src;
-      auto up = [&](int s, double t, double su) {
-        const double v = gsum<CW>(wfac * U);
+      real U = I * (real(1) - eps) + eps * sfc_src;
+      auto up = [&](int s, real t, real su) {
+        const real v = gsum<real, CW>(wfac * U);
         acc_add(&acc_up[(s + 1) * CW + cl], v, owner);
         U = t * U + su;
       };
@@ -203,7 +220,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         for (int s = nlay - 1; s >= 0; --s) up(s, sT[(long)s * 64], sSU[(long)s * 64]);
       }
       {
-        const double v = gsum<CW>(wfac * U);
+        const real v = gsum<real, CW>(wfac * U);
         acc_add(&acc_up[cl], v, owner);
       }
     }
@@ -212,8 +229,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     if (valid) {
       for (int s = gs; s < nlev; s += GW) {
         const long q = col + (long)ncol * (lev0 + lstep * s);
-        a.flux_dn[q] = acc_dn[s * CW + cl];
-        a.flux_up[q] = acc_up[s * CW + cl];
+        Q(a.flux_dn)[q] = (real)acc_dn[s * CW + cl];
+        Q(a.flux_up)[q] = (real)acc_up[s * CW + cl];
       }
     }
   }
@@ -221,9 +238,9 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
 
 constexpr int kGenericWaves = 4096;
 
-template <int NL, int CW>
+template <typename real, int NL, int CW>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<NL, CW>;
+  auto k = rte_lw_kernel<real, NL, CW>;
   const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -248,8 +265,9 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   static_assert(kPF <= 60, "prefetch ring deeper than the layer count");
-  if (a.nlay == 60) return launch_one<60, ECCKD_LW_CW>(a, s);
-  return launch_one<0, 16>(a, s);
+  if (a.f32) return a.nlay == 60 ? launch_one<float, 60, ECCKD_LW_CW_F32>(a, s) : launch_one<float, 0, 16>(a, s);
+  if (a.nlay == 60) return launch_one<double, 60, ECCKD_LW_CW>(a, s);
+  return launch_one<double, 0, 16>(a, s);
 }
 
 }  // namespace ecckd

@@ -34,6 +34,7 @@ struct ecckd_model {
   bool finalized = false;
   int device = -1;
   double *dbuf = nullptr;               // all tables, one allocation
+  float *dbuf32 = nullptr;              // the same image in single precision (same offsets)
   size_t off_temperature = 0, off_planck = 0, off_rayleigh = 0, off_solar = 0;
   // --- ECCKD_HOST staging arena (grown on demand, serialised by mu) ---
   std::mutex mu;

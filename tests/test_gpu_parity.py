@@ -298,6 +298,51 @@ def test_modes_agree_to_a_few_ulp(pkg, gpu, lw):
         assert np.array_equal(a, b)          # Planck sources: identical in both modes
 
 
+def test_single_precision_lw_path(pkg, gpu, oracle_mod, lw, arithmetic):
+    """float32 arrays take ecckd_gas_optics_lw_f32 / ecckd_rte_lw_f32 (a host built with wp = real32).
+    Checked against the fp64 oracle with single-precision tolerances (BASELINE configs[4]: fp32 vs fp64
+    sweep): tau 2e-5 relative (where tau is not tiny), sources 2e-6 relative, fluxes 2e-3 W m-2."""
+    import torch
+    k, m = lw
+    if arithmetic == "reference_order":
+        pkg.set_arithmetic(pkg.FAST)          # the single-precision path exists in the fast mode only
+    ncol, nlay, ng = 700, 60, 32
+    cols = synthetic.columns(3, ncol, k.get_press_min())
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+    gc = pkg.GasConcs(synthetic.GAS_ORDER)
+    for n in synthetic.GAS_ORDER:
+        v = cols[n]
+        if np.isscalar(v):
+            gc.set_vmr(n, float(v))
+        elif v.ndim == 1:
+            gc.set_vmr_column(n, t32(v))
+        else:
+            gc.set_vmr(n, t32(v))
+    plev, tlay, tlev, tsfc = t32(cols["plev"]), t32(cols["tlay"]), t32(cols["tlev"]), t32(cols["tsfc"])
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=plev)
+    src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k, like=plev)
+    assert op.tau.dtype == torch.float32
+    assert k.gas_optics(None, plev, tlay, tsfc, gc, op, src, tlev=tlev) == ""
+    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=torch.float32, device=gpu),
+                             torch.empty((nlay + 1, ncol), dtype=torch.float32, device=gpu))
+    assert pkg.rte_lw(op, True, src, t32(cols["sfc_emis"][:, None]), fl) == ""
+    # oracle on the float32-rounded inputs, in double
+    r = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32), dtype=np.float64)
+    c32 = {n: (r(v) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+    tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, c32["plev"], c32["tlay"], c32["tsfc"],
+                                                           helpers.oracle_gas_items(c32), c32["tlev"])
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(c32["sfc_emis"][None], ng, 0), sfc)
+    gt = op.tau.cpu().numpy().astype(np.float64)
+    big = tau > 1e-6 * tau.max()
+    assert np.max(np.abs(gt - tau)[big] / tau[big]) < 2e-5
+    assert helpers.max_rel(src.lay_source.cpu().numpy(), lay) < 2e-6
+    assert helpers.max_rel(src.lev_source_inc.cpu().numpy(), inc) < 2e-6
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < 2e-3 and np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < 2e-3
+    # mixing precisions in one call is refused, not silently converted
+    with pytest.raises(TypeError):
+        k.gas_optics(None, plev, tlay.double(), tsfc, gc, op, src, tlev=tlev)
+
+
 def test_golden_fixture_on_gpu(pkg, gpu, lw):
     """HIP path vs the committed golden vectors (tests/golden/lw_fsck_synth16.npz)."""
     import os
