@@ -45,7 +45,6 @@ struct TauArgs {
   // launch geometry chosen by the host
   int R;                       // pressure rows of the LDS slab
   int col_chunks;              // grid.x; each block walks tiles chunk by chunk
-  int debug_nostore;           // ECCKD_DEBUG_NOSTORE=1: skip the output stores (timing experiments only)
 };
 
 // Division by a wave-uniform constant, d with its reciprocal (kernels_gas_fused.hip: udiv()).

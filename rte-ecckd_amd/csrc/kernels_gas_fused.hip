@@ -25,6 +25,7 @@
 // rows of every active table (+ the whole Planck table), rows padded to an odd length; see
 // kernels_tau.hip for the slab logic, which is the same.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -41,6 +42,17 @@ constexpr int kBlock = ECCKD_FUSED_BLOCK;
 constexpr int kWaves = kBlock / 64;
 constexpr int kSeg = 8;    // tiles between two slab-range checks (block barriers)
 constexpr int kSpan = ECCKD_FUSED_SPAN;
+
+// Compile-time loop: f(integral_constant<int, I>) for I = I0 .. N-1, as straight-line code.  The
+// item pipeline below must be fully unrolled (its buffer indices and item kinds are static);
+// `#pragma unroll` silently gives up on a body this large.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 template <typename real> __device__ __forceinline__ real selmin(real a, real b) { return a < b ? a : b; }
 template <typename real> __device__ __forceinline__ real selmax(real a, real b) { return a > b ? a : b; }
@@ -141,32 +153,40 @@ __device__ __forceinline__ float swap_adjacent(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
 }
 
-// Stores the values of two consecutive g-points (planes o0, o1 of a column-fastest array) as ONE
+// Stores the values of two consecutive g-points (planes g, g+1 of a column-fastest array) as ONE
 // 16-byte store per lane instead of two 8-byte ones: the lanes of an (even, odd) column pair
-// exchange one value, then the even lane writes both columns of plane 0 and the odd lane both
-// columns of plane 1.  Per CU the store path moves ~7 B/clk with dwordx2 and about twice that with
-// dwordx4 (the kernel was store-issue bound).  Must be called by all lanes of the wave.
-//   c: column of this lane (even lanes hold even columns); o0, o1: element offsets of (column 0,
-//   plane) ; ok: this lane's column exists; pair_ok: both columns of the pair exist.
+// exchange one value, then the even lane writes both columns of plane g and the odd lane both
+// columns of plane g+1.  Per CU the store path moves ~7 B/clk with dwordx2 and about twice that with
+// dwordx4 (the kernel was store-issue bound).  Called by all lanes of the wave, and every lane
+// stores: the item pipeline only runs for waves whose 64 columns all exist (ragged waves take the
+// per-g-point path), so the store is unconditional -- no exec mask, no skip branch, and the
+// compiler's vmcnt bookkeeping stays exact across a tile (a load may wait for "all but the last 16
+// stores" instead of "every store").
+//   base: wave-uniform pointer to (column 0, plane g); voff: per-lane BYTE offset
+//   sizeof(real) * ((c - odd) + (odd ? plane : 0)), 32 bits; the four output arrays share it.
 template <typename real>
-__device__ __forceinline__ void store_pair(real *arr, long c, long o0, long o1, real v0, real v1,
-                                           bool odd, bool ok, bool pair_ok) {
+__device__ __forceinline__ void store_pair(real *base, unsigned voff, real v0, real v1, bool odd) {
   typedef real double2_t __attribute__((ext_vector_type(2)));
   const real recv = swap_adjacent(odd ? v0 : v1);
-  if (pair_ok) {
-    double2_t out;
-    out[0] = odd ? recv : v0;
-    out[1] = odd ? v1 : recv;
-    const long ce = c - (odd ? 1 : 0);
+  double2_t out;
+  out[0] = odd ? recv : v0;
+  out[1] = odd ? v1 : recv;
+#ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
+  // Pin the plane pointer in SGPRs right here: left alone, the optimiser hoists the per-lane sum
+  // array + voff out of the loops (one 64-bit VGPR pair per array and g-pair) and adds the
+  // uniform part per store.
+  typedef __attribute__((address_space(1))) char gchar;          // global, not flat: the pin below
+  typedef __attribute__((address_space(1))) double2_t gdouble2;  // hides the pointer's origin
+  gchar *gbase = (gchar *)base;
+  asm volatile("" : "+s"(gbase));
 #ifndef ECCKD_PLAIN_STORES   // nontemporal: the outputs are written once and read by the next kernel
-    __builtin_nontemporal_store(out, reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce));
+  __builtin_nontemporal_store(out, reinterpret_cast<gdouble2 *>(gbase + voff));
 #else
-    *reinterpret_cast<double2_t *>(arr + (odd ? o1 : o0) + ce) = out;
+  *reinterpret_cast<gdouble2 *>(gbase + voff) = out;
 #endif
-  } else if (ok) {   // last column of an odd ncol
-    arr[o0 + c] = v0;
-    arr[o1 + c] = v1;
-  }
+#else
+  asm volatile("" :: "v"(out));
+#endif
 }
 
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
@@ -268,30 +288,54 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     }
     __syncthreads();
 
+    // One round of global loads per tile, issued a tile ahead of its use and BEFORE the stores of
+    // the tile in flight: vector memory operations retire in order (one vmcnt), so a load issued
+    // after a tile's 64 stores would wait for every one of them to reach memory.
+    real nx_p0, nx_p1, nx_T, nx_W[NB], nx_vlut, nx_Tl0 = real(0), nx_Tl1 = real(0);
+    auto load_inputs = [&](long tile) {
+      const long c = tile * kBlock + tid;
+      const long cc = c < ncol ? c : (long)ncol - 1;
+      nx_p0 = plev0[cc]; nx_p1 = plev1[cc];
+      nx_T = P(t.tlay)[cc + (long)ncol * j];
+#pragma unroll
+      for (int s = 0; s < NB; ++s) nx_W[s] = P(a.slot[s].vmr)[cc * a.slot[s].cs + j * a.slot[s].ls];
+      nx_vlut = P(a.slot[kTauPassGases].vmr)[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
+      if (MODE == MODE_LW && a.tlev) {
+        nx_Tl0 = P(a.tlev)[cc + (long)ncol * j];
+        nx_Tl1 = P(a.tlev)[cc + (long)ncol * (j + 1)];
+      }
+    };
+#ifndef ECCKD_FUSED_NO_PREFETCH
+    load_inputs(seg);
+    // complete them here (once per segment), so that inside the tile loop the only pending loads
+    // are the ones issued a tile ago
+    asm volatile("" : "+v"(nx_p0), "+v"(nx_p1), "+v"(nx_T), "+v"(nx_vlut), "+v"(nx_Tl0), "+v"(nx_Tl1));
+#pragma unroll
+    for (int s = 0; s < NB; ++s) asm volatile("" : "+v"(nx_W[s]));
+#endif
+
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
-      const bool valid = c < ncol && !t.debug_nostore;
+      const bool valid = c < ncol;
       const bool odd = (tid & 1) != 0;
-      const bool pair_ok = ((c | 1) < ncol) && !t.debug_nostore;   // both columns of this lane pair exist
+      const bool pair_ok = (c | 1) < ncol;   // both columns of this lane pair exist
       const long cc = c < ncol ? c : (long)ncol - 1;
-      // ---- setup: one round of global loads ----
-      const real p0 = plev0[cc], p1 = plev1[cc];
-      const real Tlayer = P(t.tlay)[cc + (long)ncol * j];
+      // ---- setup: the inputs of this tile were loaded one tile ahead (see above) ----
+#ifdef ECCKD_FUSED_NO_PREFETCH
+      load_inputs(tile);
+#endif
+      const real p0 = nx_p0, p1 = nx_p1, Tlayer = nx_T;
       real W[NB];        // per-slot vmr, then weight (:143-149); 0 for unused slots
 #pragma unroll
-      for (int s = 0; s < NB; ++s) W[s] = P(a.slot[s].vmr)[cc * a.slot[s].cs + j * a.slot[s].ls];
-      real vlut = P(a.slot[kTauPassGases].vmr)[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
-      real Tl0 = real(0), Tl1 = real(0);
-      if (MODE == MODE_LW && a.tlev) {
-        Tl0 = P(a.tlev)[cc + (long)ncol * j];
-        Tl1 = P(a.tlev)[cc + (long)ncol * (j + 1)];
-      }
+      for (int s = 0; s < NB; ++s) W[s] = nx_W[s];
+      real vlut = nx_vlut;
+      const real Tl0 = nx_Tl0, Tl1 = nx_Tl1;
 
       const PPoint<real> pp = pressure_point<real>(p0, p1, lp0, ud_dlp, np);
       const int ip0 = pp.ip0;
       const int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
-      const bool fast = __all(inslab);
+      const bool fast = __all(inslab && pair_ok);   // ragged waves (end of the column range) go the slow way
 
       const real t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
       real temperature_index = udiv(Tlayer - t0, ud_dt);
@@ -336,79 +380,112 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         ql1 = planck_point<real>(Tl1, pt0, ud_pdt, ntp, L.SP);
       }
       const real moles = dp * gw;   // :313-314 (SW)
+#ifndef ECCKD_FUSED_NO_PREFETCH
+      load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
+#endif
 
       if (fast) {
-        // The g-point work of a chunk is a static sequence of "items" -- one g-point of the
-        // look_up_table gas (8 reads), BG g-points of one bilinear slot (4*BG reads), PG g-points
-        // of the Planck sources (6*PG reads) -- software-pipelined by hand: the LDS reads of item
-        // i+1 are issued before the arithmetic of item i.  Reads are volatile (kept in program
-        // order, never paired into ds_read2_b64) and every item ends in an empty asm that pins
-        // its results, otherwise instruction selection floats all arithmetic below all reads.
-        static_assert(GC % 4 == 0, "chunks are made of g-point pairs and quads");
-        constexpr int NLI = GC / 2, NBI = NB * (GC / 4), NPI = (MODE == MODE_LW) ? GC / 2 : 0;
+        // The g-point work of a chunk is a static sequence of "items" of at most four 16-byte LDS
+        // reads (two consecutive g-points each):
+        //   look_up_table gas : (g-pair, vmr plane h)   4 corner reads, 8 FMAs  -> partial / final od
+        //   bilinear slot     : (slot, g-pair)          4 corner reads, 10 FMAs
+        //   Planck sources    : (g-pair, A|B)           A: layer + level j (4 reads), B: level j+1 (2)
+        // software-pipelined by hand: the reads of item i+1 are issued before the arithmetic of item
+        // i.  Reads are volatile (kept in program order, never paired into ds_read2_b64) and every
+        // item ends in an empty asm that pins its results, otherwise instruction selection floats
+        // all arithmetic below all reads.  Four reads per item (not eight) keep the two read buffers
+        // at 32 VGPRs.
+        static_assert(GC % 4 == 0, "chunks are made of g-point pairs");
+        constexpr int NP2 = GC / 2;                                  // g-pairs per chunk
+        constexpr int NLI = 2 * NP2, NBI = NB * NP2, NPI = (MODE == MODE_LW) ? 2 * NP2 : 0;
         constexpr int NIT = NLI + NBI + NPI;
         int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
         int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
         const int dPb = L.SB, dTb = R * L.SB;
         const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
+        // Output addressing: a uniform plane pointer (SGPRs) plus ONE per-lane 32-bit byte
+        // offset shared by all four arrays -- even lanes write their column pair in plane g, odd
+        // lanes in plane g+1 (see store_pair).  launch_gas_fused() checks that it fits 32 bits.
+        const unsigned plane = (unsigned)ncol * (unsigned)nlay;
+        const unsigned coff = (unsigned)sizeof(real) * (unsigned)cc;
+        const unsigned voff = (unsigned)sizeof(real) * ((unsigned)(c - (odd ? 1 : 0)) + (odd ? plane : 0u));
         for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
           real acc[GC];
-          if (t.accumulate) {
+          if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
+            typedef __attribute__((address_space(1))) const char gcchar;
+            typedef __attribute__((address_space(1))) const real greal;
 #pragma unroll
-            for (int g = 0; g < GC; ++g)
-              acc[g] = (FULL || gb + g < ng) ? P(t.tau)[cc + (long)ncol * (j + (long)nlay * (gb + g))] : real(0);
+            for (int g = 0; g < GC; ++g) {
+              acc[g] = real(0);
+              if (FULL || gb + g < ng) {
+                // uniform plane pointer + one 32-bit per-lane offset (see store_pair)
+                gcchar *pl = (gcchar *)(P(t.tau) + (long)ncol * (j + (long)nlay * (gb + g)));
+                asm volatile("" : "+s"(pl));
+                acc[g] = *reinterpret_cast<greal *>(pl + coff);
+              }
+            }
           } else {
 #pragma unroll
             for (int g = 0; g < GC; ++g) acc[g] = real(0);
           }
           const int pb = L.pl + gb;
-          double2_t buf[2][8];
-#pragma unroll
-          for (int it = 0; it <= NIT; ++it) {
+          const long oj = (long)ncol * (j + (long)nlay * gb);   // (column 0, layer j, g-point gb)
+          double2_t buf[2][4];
+          real lutp[2] = {real(0), real(0)};
+          static_for<0, NIT + 1>([&](auto it_c) __attribute__((always_inline)) {
+            constexpr int it = decltype(it_c)::value;
             // ---------------- issue the reads of item `it` ----------------
-            if (it < NLI) {                       // look_up_table gas, g-points 2*it, 2*it+1
-              const int g = 2 * it;
+            if constexpr (it < NLI) {                       // look_up_table gas: g-points 2*pr, 2*pr+1, vmr plane h
+              const int g = 2 * (it / 2), h = it & 1;
               double2_t *b = buf[it & 1];
-              b[0] = ld2(ol + g);             b[1] = ld2(ol + dPl + g);
-              b[2] = ld2(ol + dTl + g);       b[3] = ld2(ol + dTl + dPl + g);
-              b[4] = ld2(ol + dVl + g);       b[5] = ld2(ol + dVl + dPl + g);
-              b[6] = ld2(ol + dVl + dTl + g); b[7] = ld2(ol + dVl + dTl + dPl + g);
-            } else if (it < NLI + NBI) {          // one bilinear slot, 4 g-points
-              const int s = (it - NLI) / (GC / 4), g0 = ((it - NLI) % (GC / 4)) * 4;
+              const int o = ol + h * dVl + g;
+              b[0] = ld2(o); b[1] = ld2(o + dPl); b[2] = ld2(o + dTl); b[3] = ld2(o + dTl + dPl);
+            } else if constexpr (it < NLI + NBI) {          // one bilinear slot, one g-pair
+              const int s = (it - NLI) / NP2, g = 2 * ((it - NLI) % NP2);
               double2_t *b = buf[it & 1];
-              const int o = ob + s * ngp + g0;
-              b[0] = ld2(o);       b[1] = ld2(o + dPb);       b[2] = ld2(o + dTb);     b[3] = ld2(o + dTb + dPb);
-              b[4] = ld2(o + 2);   b[5] = ld2(o + dPb + 2);   b[6] = ld2(o + dTb + 2); b[7] = ld2(o + dTb + dPb + 2);
-            } else if (it < NIT) {                // Planck sources, 2 g-points
-              const int g = 2 * (it - NLI - NBI);
+              const int o = ob + s * ngp + g;
+              b[0] = ld2(o); b[1] = ld2(o + dPb); b[2] = ld2(o + dTb); b[3] = ld2(o + dTb + dPb);
+            } else if constexpr (it < NIT) {                // Planck sources of one g-pair, half A or B
+              const int k = it - NLI - NBI, g = 2 * (k / 2);
               double2_t *b = buf[it & 1];
-              b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
-              b[2] = ld2(pb + ql0.off + g);  b[3] = ld2(pb + ql0.off + L.SP + g);
-              b[4] = ld2(pb + ql1.off + g);  b[5] = ld2(pb + ql1.off + L.SP + g);
+              if ((k & 1) == 0) {
+                b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
+                b[2] = ld2(pb + ql0.off + g);  b[3] = ld2(pb + ql0.off + L.SP + g);
+              } else {
+                b[0] = ld2(pb + ql1.off + g);  b[1] = ld2(pb + ql1.off + L.SP + g);
+              }
             }
             // ---------------- arithmetic of item `it - 1` ----------------
-            if (it >= 1) {
-              const int pi_ = it - 1;
+            if constexpr (it >= 1) {
+              constexpr int pi_ = it - 1;
               const double2_t *b = buf[pi_ & 1];
-              if (pi_ < NLI) {
+              if constexpr (pi_ < NLI) {
+                const int g0 = 2 * (pi_ / 2);
+                if ((pi_ & 1) == 0) {
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    real v = l000 * b[0][q];
+                    v = fma(l100, b[1][q], v); v = fma(l010, b[2][q], v); v = fma(l110, b[3][q], v);
+                    asm volatile("" : "+v"(v));
+                    lutp[q] = v;
+                  }
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    real v = lutp[q];
+                    v = fma(l001, b[0][q], v); v = fma(l101, b[1][q], v); v = fma(l011, b[2][q], v);
+                    v = fma(l111, b[3][q], v);
+                    if (ANYCLAMP) { v = vlut * v; v = v < real(0) ? real(0) : v; }
+                    acc[g0 + q] = acc[g0 + q] + v;
+                    asm volatile("" : "+v"(acc[g0 + q]));
+                  }
+                }
+              } else if constexpr (pi_ < NLI + NBI) {
+                const int s = (pi_ - NLI) / NP2, g0 = 2 * ((pi_ - NLI) % NP2);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                  const int g = 2 * pi_ + q;
-                  real v = l000 * b[0][q];
-                  v = fma(l100, b[1][q], v); v = fma(l010, b[2][q], v); v = fma(l110, b[3][q], v);
-                  v = fma(l001, b[4][q], v); v = fma(l101, b[5][q], v); v = fma(l011, b[6][q], v);
-                  v = fma(l111, b[7][q], v);
-                  if (ANYCLAMP) { v = vlut * v; v = v < real(0) ? real(0) : v; }
-                  acc[g] = acc[g] + v;
-                  asm volatile("" : "+v"(acc[g]));
-                }
-              } else if (pi_ < NLI + NBI) {
-                const int s = (pi_ - NLI) / (GC / 4), g0 = ((pi_ - NLI) % (GC / 4)) * 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const int h = (q >> 1) * 4, e = q & 1;
-                  real v = a00 * b[h][e];
-                  v = fma(a10, b[h + 1][e], v); v = fma(a01, b[h + 2][e], v); v = fma(a11, b[h + 3][e], v);
+                  real v = a00 * b[0][q];
+                  v = fma(a10, b[1][q], v); v = fma(a01, b[2][q], v); v = fma(a11, b[3][q], v);
                   if (ANYCLAMP) { v = W[s] * v; v = v < real(0) ? real(0) : v; acc[g0 + q] = acc[g0 + q] + v; }
                   else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
                   asm volatile("" : "+v"(acc[g0 + q]));
@@ -417,19 +494,19 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int g = 0; g < GC; g += 2) {
                     if (FULL || gb + g + 1 < ng) {
-                      const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
+                      const long og = oj + (long)plane * g;
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair<real>(Q(t.tau), c, o0, o1, t0_, t1_, odd, valid, pair_ok);
+                        store_pair<real>(Q(t.tau) + og, voff, t0_, t1_, odd);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair<real>(Q(t.ssa), c, o0, o1, r0 / t0_, r1 / t1_, odd, valid, pair_ok);
-                          store_pair<real>(Q(t.g), c, o0, o1, real(0), real(0), odd, valid, pair_ok);
+                          store_pair<real>(Q(t.ssa) + og, voff, r0 / t0_, r1 / t1_, odd);
+                          store_pair<real>(Q(t.g) + og, voff, real(0), real(0), odd);
                         }
                       } else {
-                        store_pair<real>(Q(t.tau), c, o0, o1, acc[g], acc[g + 1], odd, valid, pair_ok);
+                        store_pair<real>(Q(t.tau) + og, voff, acc[g], acc[g + 1], odd);
                       }
-                    } else if (gb + g < ng && valid) {   // odd ng: last g-point alone
+                    } else if (gb + g < ng) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
                       if (MODE == MODE_SW) {
                         const real ray = moles * P(t.rayleigh)[gb + g];
@@ -443,29 +520,36 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   }
                 }
               } else {
-                const int g = 2 * (pi_ - NLI - NBI);
-                real vl[2], v0[2], v1[2];
+                const int k = pi_ - NLI - NBI, g = 2 * (k / 2);
+                const bool both = FULL || gb + g + 1 < ng;
+                const long og = oj + (long)plane * g;
+                const long o1 = c + (long)ncol * (j + (long)nlay * (gb + g));   // odd ng: last g-point alone
+                if ((k & 1) == 0) {
+                  real vl[2], v0[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                  vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
-                  v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
-                  v1[q] = div_pi(ql1.w0 * b[4][q] + ql1.w1 * b[5][q], pi, rpi);
-                }
-                if (FULL || gb + g + 1 < ng) {
-                  const long o0 = (long)ncol * (j + (long)nlay * (gb + g)), o1 = o0 + (long)ncol * nlay;
-                  store_pair<real>(Q(a.lay_source), c, o0, o1, vl[0], vl[1], odd, valid, pair_ok);
-                  if (a.tlev) {                                                      // :423-424
-                    store_pair<real>(Q(a.lev_source_dec), c, o0, o1, v0[0], v0[1], odd, valid, pair_ok);
-                    store_pair<real>(Q(a.lev_source_inc), c, o0, o1, v1[0], v1[1], odd, valid, pair_ok);
+                  for (int q = 0; q < 2; ++q) {
+                    vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
+                    v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
                   }
-                } else if (gb + g < ng && valid) {
-                  const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
-                  Q(a.lay_source)[o] = vl[0];
-                  if (a.tlev) { Q(a.lev_source_dec)[o] = v0[0]; Q(a.lev_source_inc)[o] = v1[0]; }
+                  if (both) {
+                    store_pair<real>(Q(a.lay_source) + og, voff, vl[0], vl[1], odd);
+                    if (a.tlev) store_pair<real>(Q(a.lev_source_dec) + og, voff, v0[0], v0[1], odd);   // :423
+                  } else if (gb + g < ng) {
+                    Q(a.lay_source)[o1] = vl[0];
+                    if (a.tlev) Q(a.lev_source_dec)[o1] = v0[0];
+                  }
+                } else {
+                  real v1[2];
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) v1[q] = div_pi(ql1.w0 * b[0][q] + ql1.w1 * b[1][q], pi, rpi);
+                  if (a.tlev) {                                                      // :424
+                    if (both) store_pair<real>(Q(a.lev_source_inc) + og, voff, v1[0], v1[1], odd);
+                    else if (gb + g < ng) Q(a.lev_source_inc)[o1] = v1[0];
+                  }
                 }
               }
             }
-          }
+          });
         }
       } else {
         // ---- a lane of this wave is outside the staged rows: tables from global memory ----
@@ -624,10 +708,9 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   }
   if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;
   if (t.nseq > kTauPassGases) return hipErrorInvalidValue;
-  {
-    const char *e = getenv("ECCKD_DEBUG_NOSTORE");
-    t.debug_nostore = (e && e[0] == '1') ? 1 : 0;
-  }
+  // store_pair() addresses a plane pair with a 32-bit byte offset
+  if (((size_t)t.ncol * (size_t)t.nlay + (size_t)t.ncol) * (a.f32 ? sizeof(float) : sizeof(double)) >= (size_t)0xFFFFFFF0u)
+    return hipErrorInvalidValue;
   const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
   const int ntp = a.mode == MODE_LW ? a.ntp : 0;
   bool anyclamp = false;
