@@ -214,11 +214,12 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     if (fast) {
       fa.mode = (sw && last) ? 2 : 0;
       const int nv_lut = a.lut >= 0 ? a.seq[a.lut].nv : 0;
-      // Planck sources ride along with the first pass when the table fits next to >= 3 slab rows
+      // Planck sources ride along with the first pass when the table, or a window of it, fits next
+      // to >= 3 slab rows
       int pass_clamp = 0;
       for (int k = 0; k < a.nseq; ++k) pass_clamp |= a.seq[k].clamp;
       if (pl && first_pass && !sw &&
-          fused_slab_rows(a.ng, a.np, a.nt, a.nbil, nv_lut, m->ntp, 3, pass_clamp, g_f32) > 0) {
+          fused_planck_rows(a.ng, a.np, a.nt, a.nbil, nv_lut, m->ntp, pass_clamp, g_f32) > 0) {
         fa.mode = 1;
         fa.ntp = m->ntp;
         fa.planck = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_planck) : m->dbuf + m->off_planck;

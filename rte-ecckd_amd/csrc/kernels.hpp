@@ -68,6 +68,7 @@ struct FusedArgs {
   int f32;                     // 1: every data pointer addresses float arrays (LW fused path only)
   int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
   int ntp;
+  int pw;                      // Planck rows staged in LDS (ntp, or a window); filled by launch_gas_fused
   const double *planck;        // (ng,ntp) device
   double pt0, pdt;             // temperature_planck(1), (2)-(1)
   const double *tlev, *tsfc;   // tlev may be nullptr
@@ -112,7 +113,8 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp, int f32);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32);
+int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int anyclamp, int f32);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);

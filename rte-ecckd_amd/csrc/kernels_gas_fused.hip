@@ -69,11 +69,12 @@ __host__ __device__ inline int row_stride(int n) { return n + ((6 - (n & 3)) & 3
 // NB  = bilinear slots the kernel reads per row (>= nbil; the slab is followed by a pad so that the
 //       zero-weight slots read finite data).
 // ngp = g-points per row in LDS: ng rounded up to the chunk size GC (the tail stays zero).
+// ntp = Planck rows held in LDS (the whole table, or the window FusedArgs::pw).
 __host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp) {
   FLayout L;
   L.tb = 0;
   L.red = (np + 1) & ~1;
-  L.bil = L.red + 2 * kWaves;
+  L.bil = L.red + 4 * kWaves;
   L.SB = nbil > 0 ? row_stride(nbil * ngp) : 2;
   L.lut = L.bil + R * nt * L.SB + NB * ngp;
   L.SL = nv_lut > 0 ? row_stride(ngp) : 2;
@@ -114,10 +115,12 @@ template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(
   return r;
 }
 
-// Planck interpolation point (:275-285).  Below the table the reference uses (T/t0)*B(:,1); that
-// is row 0 with weights (T/t0, 0): w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.
-template <typename real> struct PlPoint { int off; real w0, w1; };
-template <typename real> __device__ __forceinline__ PlPoint<real> planck_point(real Tk, real t0, const UDivT<real> &dt, int ntp, int SP) {
+// Planck interpolation point (:275-285): rows `row`, `row + 1` of the table (0-based) with weights
+// w0, w1.  Below the table the reference uses (T/t0)*B(:,1); that is row 0 with weights (T/t0, 0):
+// w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.  `off` is filled in by the caller (LDS
+// offset of the row inside the staged window).
+template <typename real> struct PlPoint { int row, off; real w0, w1; };
+template <typename real> __device__ __forceinline__ PlPoint<real> planck_point(real Tk, real t0, const UDivT<real> &dt, int ntp) {
   PlPoint<real> p;
   real temperature_index = udiv(Tk - t0, dt);
   if (temperature_index >= 0) {
@@ -125,12 +128,13 @@ template <typename real> __device__ __forceinline__ PlPoint<real> planck_point(r
     const int it0 = temperature_index >= (real)(ntp - 1) ? ntp - 1 : (int)temperature_index;
     p.w1 = temperature_index - it0;
     p.w0 = real(1) - p.w1;
-    p.off = (it0 - 1) * SP;
+    p.row = it0 - 1;
   } else {
     p.w0 = Tk / t0;
     p.w1 = real(0);
-    p.off = 0;
+    p.row = 0;
   }
+  p.off = 0;
   return p;
 }
 
@@ -205,8 +209,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   const int ncol = t.ncol, nlay = t.nlay, ng = t.ng, np = t.np, nt = t.nt, R = t.R;
   const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
   const int ntp = MODE == MODE_LW ? a.ntp : 0;
+  const int PW = MODE == MODE_LW ? a.pw : 0;   // Planck rows staged in LDS: ntp (whole table) or a window
   const int ngp = (ng + GC - 1) / GC * GC;
-  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, ntp);
+  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, PW);
   real *redd = lds + L.red;
   // The argument structs carry `double` pointers and scalars; in the single-precision
   // instantiation the pointers address float data (host side casts) and the scalars are rounded.
@@ -221,12 +226,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   for (int i = tid; i < L.total; i += kBlock) lds[i] = real(0);
   __syncthreads();
   for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = P(t.temperature)[i];
-  if (MODE == MODE_LW) {
-    for (int q = tid; q < ntp * ng; q += kBlock) {
-      const int r = q / ng, g = q - r * ng;
-      lds[L.pl + r * L.SP + g] = P(a.planck)[q];
-    }
-  }
+  int pw_lo = -1;   // first table row of the staged Planck window (-1: nothing staged yet)
 
   const long ntiles = ((long)ncol + kBlock - 1) / kBlock;
   const long t_begin = ntiles * blockIdx.x / gridDim.x;
@@ -238,26 +238,70 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   for (long seg = t_begin; seg < t_end; seg += kSeg) {
     const long seg_end = seg + kSeg < t_end ? seg + kSeg : t_end;
     // ---- pre-pass: range of p0+p1 over the segment; the pressure index is monotone in it ----
-    real smin = real(3.0e38), smax = -real(3.0e38);
+    // ... and, when only a window of the Planck table is staged, the range of the temperatures that
+    // index it (layer j and its two levels); the table row is monotone in T.
+    const bool windowed = MODE == MODE_LW && PW < ntp;
+    real smin = real(3.0e38), smax = -real(3.0e38), tmin = real(3.0e38), tmax = -real(3.0e38);
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
       if (c < ncol) {
         const real sp = plev1[c] + plev0[c];
         smin = selmin(smin, sp);
         smax = selmax(smax, sp);
+        if (windowed) {
+          const real tl = P(t.tlay)[c + (long)ncol * j];
+          tmin = selmin(tmin, tl);
+          tmax = selmax(tmax, tl);
+          if (a.tlev) {
+            const real ta = P(a.tlev)[c + (long)ncol * j], tb = P(a.tlev)[c + (long)ncol * (j + 1)];
+            tmin = selmin(tmin, selmin(ta, tb));
+            tmax = selmax(tmax, selmax(ta, tb));
+          }
+        }
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       smin = selmin(smin, __shfl_xor(smin, o));
       smax = selmax(smax, __shfl_xor(smax, o));
+      if (windowed) {
+        tmin = selmin(tmin, __shfl_xor(tmin, o));
+        tmax = selmax(tmax, __shfl_xor(tmax, o));
+      }
     }
     __syncthreads();   // the previous segment's LDS reads are done
-    if (lane == 0) { redd[2 * wave] = smin; redd[2 * wave + 1] = smax; }
+    if (lane == 0) { redd[4 * wave] = smin; redd[4 * wave + 1] = smax; redd[4 * wave + 2] = tmin; redd[4 * wave + 3] = tmax; }
     __syncthreads();
-    smin = redd[0]; smax = redd[1];
+    smin = redd[0]; smax = redd[1]; tmin = redd[2]; tmax = redd[3];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) { smin = selmin(smin, redd[2 * w]); smax = selmax(smax, redd[2 * w + 1]); }
+    for (int w = 1; w < kWaves; ++w) {
+      smin = selmin(smin, redd[4 * w]); smax = selmax(smax, redd[4 * w + 1]);
+      tmin = selmin(tmin, redd[4 * w + 2]); tmax = selmax(tmax, redd[4 * w + 3]);
+    }
+    if (MODE == MODE_LW) {
+      // rows [pw_lo, pw_lo + PW) of the Planck table; a lane needs rows r and r + 1
+      int want = pw_lo;
+      if (!windowed) {
+        want = 0;
+      } else if (tmin <= tmax) {
+        const int rlo = planck_point<real>(tmin, pt0, ud_pdt, ntp).row, rhi = planck_point<real>(tmax, pt0, ud_pdt, ntp).row + 1;
+        if (pw_lo < 0 || rlo < pw_lo || rhi > pw_lo + PW - 1) {
+          // centre the range if it fits, else start at its low end (the rest takes the slow path)
+          const int slack = PW - (rhi - rlo + 1);
+          want = rlo - (slack > 0 ? slack / 2 : 0);
+          want = want < 0 ? 0 : (want > ntp - PW ? ntp - PW : want);
+        }
+      } else if (pw_lo < 0) {
+        want = 0;
+      }
+      if (want != pw_lo) {   // block-uniform: every thread holds the same reduced range
+        pw_lo = want;
+        for (int q = tid; q < PW * ng; q += kBlock) {
+          const int r = q / ng, g = q - r * ng;
+          lds[L.pl + r * L.SP + g] = P(a.planck)[(long)(pw_lo + r) * ng + g];
+        }
+      }
+    }
     int ipmin = 1, ipmax = 0;
     if (smin <= smax) {
       // same expression as pressure_point(): log(0.5*(p1+p0)); 0 + s == s exactly
@@ -335,7 +379,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const int ip0 = pp.ip0;
       const int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
-      const bool fast = __all(inslab && pair_ok);   // ragged waves (end of the column range) go the slow way
 
       const real t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
       real temperature_index = udiv(Tlayer - t0, ud_dt);
@@ -373,13 +416,21 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         if (!ANYCLAMP) x = x < real(0) ? real(0) : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
         W[s] = s < t.nbil ? x : real(0);
       }
-      PlPoint<real> qlay{0, real(0), real(0)}, ql0{0, real(0), real(0)}, ql1{0, real(0), real(0)};
+      PlPoint<real> qlay{0, 0, real(0), real(0)}, ql0{0, 0, real(0), real(0)}, ql1{0, 0, real(0), real(0)};
+      bool inwin = true;
       if (MODE == MODE_LW) {
-        qlay = planck_point<real>(Tlayer, pt0, ud_pdt, ntp, L.SP);
-        ql0 = planck_point<real>(Tl0, pt0, ud_pdt, ntp, L.SP);
-        ql1 = planck_point<real>(Tl1, pt0, ud_pdt, ntp, L.SP);
+        qlay = planck_point<real>(Tlayer, pt0, ud_pdt, ntp);
+        ql0 = a.tlev ? planck_point<real>(Tl0, pt0, ud_pdt, ntp) : qlay;
+        ql1 = a.tlev ? planck_point<real>(Tl1, pt0, ud_pdt, ntp) : qlay;
+        const int rmin = min(qlay.row, min(ql0.row, ql1.row)), rmax = max(qlay.row, max(ql0.row, ql1.row));
+        inwin = rmin >= pw_lo && rmax + 1 <= pw_lo + PW - 1;
+        qlay.off = (qlay.row - pw_lo) * L.SP;
+        ql0.off = (ql0.row - pw_lo) * L.SP;
+        ql1.off = (ql1.row - pw_lo) * L.SP;
       }
       const real moles = dp * gw;   // :313-314 (SW)
+      // ragged waves (end of the column range) and waves outside the staged rows go the slow way
+      const bool fast = __all(inslab && pair_ok && inwin);
 #ifndef ECCKD_FUSED_NO_PREFETCH
       load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
 #endif
@@ -594,11 +645,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
               Q(t.tau)[o] = acc;
             }
             if (MODE == MODE_LW) {
-              const int pb = L.pl + g;
-              Q(a.lay_source)[o] = div_pi(qlay.w0 * lv[pb + qlay.off] + qlay.w1 * lv[pb + qlay.off + L.SP], pi, rpi);
+              const real *pg = P(a.planck) + g;   // table rows from global memory: any row, staged or not
+              Q(a.lay_source)[o] = div_pi(qlay.w0 * pg[(long)qlay.row * ng] + qlay.w1 * pg[(long)(qlay.row + 1) * ng], pi, rpi);
               if (a.tlev) {
-                Q(a.lev_source_dec)[o] = div_pi(ql0.w0 * lv[pb + ql0.off] + ql0.w1 * lv[pb + ql0.off + L.SP], pi, rpi);
-                Q(a.lev_source_inc)[o] = div_pi(ql1.w0 * lv[pb + ql1.off] + ql1.w1 * lv[pb + ql1.off + L.SP], pi, rpi);
+                Q(a.lev_source_dec)[o] = div_pi(ql0.w0 * pg[(long)ql0.row * ng] + ql0.w1 * pg[(long)(ql0.row + 1) * ng], pi, rpi);
+                Q(a.lev_source_inc)[o] = div_pi(ql1.w0 * pg[(long)ql1.row * ng] + ql1.w1 * pg[(long)(ql1.row + 1) * ng], pi, rpi);
               }
             }
           }
@@ -607,10 +658,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       // ---- surface source (:408-413), by the blocks of the first layer ----
       if (MODE == MODE_LW && j == 0 && valid) {
-        const PlPoint<real> qs = planck_point<real>(P(a.tsfc)[c], pt0, ud_pdt, ntp, L.SP);
+        // (table rows from global memory: the surface temperature is not part of the window range)
+        const PlPoint<real> qs = planck_point<real>(P(a.tsfc)[c], pt0, ud_pdt, ntp);
+        const real *p0r = P(a.planck) + (long)qs.row * ng, *p1r = p0r + ng;
         for (int g = 0; g < ng; ++g)
-          Q(a.sfc_source)[c + (long)ncol * g] =
-              div_pi(qs.w0 * lv[L.pl + qs.off + g] + qs.w1 * lv[L.pl + qs.off + L.SP + g], pi, rpi);
+          Q(a.sfc_source)[c + (long)ncol * g] = div_pi(qs.w0 * p0r[g] + qs.w1 * p1r[g], pi, rpi);
       }
     }
   }
@@ -657,18 +709,35 @@ void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
 
 }  // namespace
 
-// Rows of the LDS slab for a fused launch, or 0 if it does not fit with at least `min_rows`.
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int min_rows, int anyclamp, int f32) {
+// Rows of the LDS slab for a fused launch that keeps `pl_rows` rows of the Planck table in LDS, or 0
+// if it does not fit with at least `min_rows`.
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32) {
   int GC, NB;
   pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
   const int ngp = (ng + GC - 1) / GC * GC;
   const size_t esz = f32 ? sizeof(float) : sizeof(double);
   int R = 0;
   for (int r = 2; r <= np; ++r) {
-    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, ntp).total <= (size_t)kLdsBudget) R = r;
+    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows).total <= (size_t)kLdsBudget) R = r;
     else break;
   }
   return R >= min_rows ? R : 0;
+}
+
+// Planck rows to stage for a fused longwave launch: the whole table if it fits next to >= 3 slab
+// rows, else the largest window of the list that does (a segment of 4096 columns of one layer
+// rarely spans more than ~70 K = 70 rows of the 1 K table); 0 = does not fit at all.
+// ECCKD_PLANCK_WINDOW=<rows> forces a window (tests of the out-of-window path).
+int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int anyclamp, int f32) {
+  if (ntp < 2) return 0;
+  if (const char *e = getenv("ECCKD_PLANCK_WINDOW")) {
+    const int w = atoi(e);
+    if (w >= 2 && w < ntp && fused_slab_rows(ng, np, nt, nbil, nv_lut, w, 3, anyclamp, f32) > 0) return w;
+  }
+  if (fused_slab_rows(ng, np, nt, nbil, nv_lut, ntp, 3, anyclamp, f32) > 0) return ntp;
+  for (int w : {128, 96, 64, 48, 32, 16})
+    if (w < ntp && fused_slab_rows(ng, np, nt, nbil, nv_lut, w, 3, anyclamp, f32) > 0) return w;
+  return 0;
 }
 
 UDiv make_udiv(double d, int f32) {
@@ -712,14 +781,19 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   if (((size_t)t.ncol * (size_t)t.nlay + (size_t)t.ncol) * (a.f32 ? sizeof(float) : sizeof(double)) >= (size_t)0xFFFFFFF0u)
     return hipErrorInvalidValue;
   const int nv_lut = t.lut >= 0 ? t.seq[t.lut].nv : 0;
-  const int ntp = a.mode == MODE_LW ? a.ntp : 0;
   bool anyclamp = false;
   for (int k = 0; k < t.nseq; ++k) anyclamp |= t.seq[k].clamp != 0;
+  if (a.mode == MODE_LW) {
+    a.pw = fused_planck_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.ntp, anyclamp, a.f32);
+    if (a.pw < 2) return hipErrorInvalidValue;   // the caller checks fused_planck_rows() first
+  } else {
+    a.pw = 0;
+  }
   int GC, NB;
   pick_shape(t.ng, t.nbil, anyclamp, &GC, &NB);
   const int ngp = (t.ng + GC - 1) / GC * GC;
-  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, ntp, 0, anyclamp, a.f32);
-  const size_t lds = (a.f32 ? sizeof(float) : sizeof(double)) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, ntp).total;
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, a.f32);
+  const size_t lds = (a.f32 ? sizeof(float) : sizeof(double)) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw).total;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full

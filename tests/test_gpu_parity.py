@@ -243,6 +243,23 @@ def test_lw_36g_16band_model(pkg, gpu, oracle_mod):
     assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
 
 
+@pytest.mark.parametrize("window", ["16", "48"])
+def test_planck_window_smaller_than_the_temperature_range(pkg, gpu, oracle_mod, lw, window, monkeypatch):
+    """The fused kernel may stage only a window of the Planck table in LDS (it does for the 36-g file);
+    ECCKD_PLANCK_WINDOW forces a small one on the 32-g model so that, with the 60 K + edge-case temperature
+    spread of these columns, most waves take the out-of-window path.  Sources must stay bit-identical."""
+    k, m = lw
+    monkeypatch.setenv("ECCKD_PLANCK_WINDOW", window)
+    check_lw(pkg, k, m, oracle_mod, synthetic.columns(11, 1500, k.get_press_min()), gpu)
+    check_lw(pkg, k, m, oracle_mod, edge_columns(k.get_press_min()), gpu)
+    cold_to_hot = synthetic.columns(3, 640, k.get_press_min())     # a ramp: every wave in a different window
+    ramp = np.linspace(-60.0, 60.0, 640)[None, :]
+    for f in ("tlev", "tlay"):
+        cold_to_hot[f] = cold_to_hot[f] + ramp
+    cold_to_hot["tsfc"] = cold_to_hot["tsfc"] + ramp[0]
+    check_lw(pkg, k, m, oracle_mod, cold_to_hot, gpu)
+
+
 def test_sw_gas_optics_and_rte_sw(pkg, gpu, oracle_mod):
     import torch
     k = pkg.GasOpticsEcckd()
