@@ -7,12 +7,12 @@
 //
 // Mapping (gfx950): as the LW solver -- one wave = CW columns x GW=64/CW g-points, lanes that
 // share a column are summed with a wave shuffle butterfly into wave-private LDS accumulators.
-// Two passes per (column, g-point): bottom->top computes the two-stream coefficients ONCE and runs
-// the adding recurrences with the source normalised by the direct beam (which is only known on the
-// way down); top->bottom propagates the direct beam and the fluxes.  The four per-layer and two
-// per-level quantities the second pass needs go through a per-wave global scratch ring
-// ([array][layer][lane], 512 B coalesced rows; 4096 waves x 187 KB): 120 B/cell of traffic in all.
-// (Registers cannot hold them next to a useful occupancy: the coefficient arithmetic is ~300 fp64
+// Two passes per (column, g-point): bottom->top computes the two-stream coefficients and runs the
+// adding recurrences with the source normalised by the direct beam (which is only known on the way
+// down); top->bottom propagates the direct beam and the fluxes.  What the second pass needs goes
+// through a per-wave global scratch ring ([array][level][lane], 512 B coalesced rows); see the
+// RECOMPUTE note at the kernel for what is stored and what is computed twice.
+// (Registers cannot hold it next to a useful occupancy: the coefficient arithmetic is ~250 fp64
 // instructions per cell and needs several waves per SIMD to issue at rate.)
 #include "kernels.hpp"
 
@@ -32,6 +32,14 @@ __device__ __forceinline__ double gsum(double v) {
 #ifndef ECCKD_SW_CW
 #define ECCKD_SW_CW 16
 #endif
+#ifndef ECCKD_SW_RECOMPUTE
+#define ECCKD_SW_RECOMPUTE 1
+#endif
+constexpr bool kSwRecompute = ECCKD_SW_RECOMPUTE != 0;
+#ifndef ECCKD_SW_PF
+#define ECCKD_SW_PF 3
+#endif
+constexpr int kPF = ECCKD_SW_PF;   // layers of optical properties in flight per lane
 constexpr int kSwWaves = ECCKD_SW_WAVES;
 
 // acc += v by the owner lane only (the other lanes add +0.0): one fire-and-forget ds_add_f64,
@@ -40,7 +48,44 @@ __device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
   __hip_atomic_fetch_add(p, owner ? v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <int CW>
+// sw_two_stream for one cell: Zdunkowski PIFM coefficients, diffuse and direct reflectance and
+// transmittance, direct-beam transmittance.
+struct TwoStream { double Rdif, Tdif, Rdir, Tdir, Tnoscat; };
+__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq, double mu0, double mu0_inv) {
+  const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
+  const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
+  const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
+  const double gamma3 = (2. - 3. * mu0 * gq) * .25;
+  const double gamma4 = 1. - gamma3;
+  const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+  const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+  const double kk0 = (gamma1 - gamma2) * (gamma1 + gamma2);
+  const double k = sqrt(kk0 > 1.e-12 ? kk0 : 1.e-12);
+  const double exp_minusktau = exp(-tau * k);
+  const double exp_minus2ktau = exp_minusktau * exp_minusktau;
+  double RT_term = 1. / (k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
+  TwoStream r;
+  r.Rdif = RT_term * gamma2 * (1. - exp_minus2ktau);
+  r.Tdif = RT_term * 2. * k * exp_minusktau;
+  r.Tnoscat = exp(-tau * mu0_inv);
+  const double k_mu = k * mu0, k_gamma3 = k * gamma3, k_gamma4 = k * gamma4;
+  const double d = 1. - k_mu * k_mu;
+  RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
+  r.Rdir = RT_term * ((1. - k_mu) * (alpha2 + k_gamma3) - (1. + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
+                      2.0 * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * r.Tnoscat);
+  r.Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * r.Tnoscat -
+                       (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * r.Tnoscat -
+                       2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+  return r;
+}
+
+// RECOMPUTE = true: pass 2 reads tau/ssa/g again and recomputes the two-stream coefficients; only the
+// two per-level quantities go through the scratch ring (24 + 16 + 24 + 16 = 80 B/cell of traffic,
+// twice the arithmetic).  RECOMPUTE = false: pass 1 stores the four per-layer products pass 2
+// needs as well (24 + 48 + 48 = 120 B/cell).  The kernel is bound by that traffic, not by the
+// arithmetic (0.25 VALU wave-instr/clk/CU of 0.81 available at this occupancy): measured 4.52 ms
+// stored vs 3.85 ms recomputed per 1e5 columns x 27 g-points (recomputed: 52 % of the fp64 VALU rate).
+template <int CW, bool RECOMPUTE>
 __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   constexpr int GW = 64 / CW;
   extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
@@ -51,11 +96,12 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   double *acc_up = acc, *acc_dn = acc + nlev * CW, *acc_dir = acc + 2 * nlev * CW;
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
   const long lstep = a.top_at_1 ? 1 : -1;
-  const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
-  // scratch ring of this wave: 4 layer arrays + 2 level arrays, each [index][64 lanes]
-  double *sc = a.scratch + (long)blockIdx.x * (4L * nlay + 2L * nlev) * 64 + lane;
-  double *sA = sc, *sB = sc + 64L * nlay, *sC = sc + 128L * nlay, *sTn = sc + 192L * nlay;
-  double *sAlb = sc + 256L * nlay, *sSrc = sAlb + 64L * nlev;
+  // scratch ring of this wave: level arrays (albedo, normalised source) first, then -- unless they
+  // are recomputed -- the four layer arrays; each [index][64 lanes]
+  constexpr int NLAYARR = RECOMPUTE ? 0 : 4;
+  double *sc = a.scratch + (long)blockIdx.x * ((long)NLAYARR * nlay + 2L * nlev) * 64 + lane;
+  double *sAlb = sc, *sSrc = sc + 64L * nlev;
+  double *sA = sSrc + 64L * nlev, *sB = sA + 64L * nlay, *sC = sB + 64L * nlay, *sTn = sC + 64L * nlay;
   const int ngroups = (ng + GW - 1) / GW;
   const long ntiles = ((long)ncol + CW - 1) / CW;
 
@@ -79,45 +125,38 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
       // recurrences (albedo, source of upward radiation).  The direct beam is not known yet on the
       // way up, so the source is carried normalised by the direct flux at its own level:
       //   src(l) = nsrc(l) * F_dir(l),  F_dir(l+1) = Tnoscat(l) * F_dir(l)
-      // and the three products the downward sweep needs are stored once per layer.
       double albedo = a.alb_dif[band + (long)a.nband * cc];
       double nsrc = a.alb_dir[band + (long)a.nband * cc];   // src_sfc = F_dir(sfc) * sfc_alb_dir
       sAlb[64L * nlay] = albedo;
       sSrc[64L * nlay] = nsrc;
+      // (the optical properties of layer s - kPF are requested before the arithmetic of layer s: the
+      // loop is a serial recurrence and the compiler does not pipeline it)
+      double ptau[kPF], pssa[kPF], pg[kPF];
+#pragma unroll
+      for (int d = 0; d < kPF; ++d) {
+        const int sl = nlay - 1 - d > 0 ? nlay - 1 - d : 0;
+        const long q = base + (long)ncol * (lay0 + lstep * sl);
+        ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
+      }
       for (int s = nlay - 1; s >= 0; --s) {
-        const long q = base + (long)ncol * (lay0 + lstep * s);
-        const double tau = a.tau[q], w0 = a.ssa[q], gq = a.g[q];
-        const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
-        const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
-        const double gamma3 = (2. - 3. * mu0 * gq) * .25;
-        const double gamma4 = 1. - gamma3;
-        const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
-        const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-        const double kk0 = (gamma1 - gamma2) * (gamma1 + gamma2);
-        const double k = sqrt(kk0 > 1.e-12 ? kk0 : 1.e-12);
-        const double exp_minusktau = exp(-tau * k);
-        const double exp_minus2ktau = exp_minusktau * exp_minusktau;
-        double RT_term = 1. / (k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
-        const double Rdif = RT_term * gamma2 * (1. - exp_minus2ktau);
-        const double Tdif = RT_term * 2. * k * exp_minusktau;
-        const double Tnoscat = exp(-tau * mu0_inv);
-        const double k_mu = k * mu0, k_gamma3 = k * gamma3, k_gamma4 = k * gamma4;
-        const double d = 1. - k_mu * k_mu;
-        RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
-        const double Rdir = RT_term * ((1. - k_mu) * (alpha2 + k_gamma3) -
-                                       (1. + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
-                                       2.0 * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * Tnoscat);
-        const double Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
-                                        (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * Tnoscat -
-                                        2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
-        const double denom = 1. / (1. - Rdif * albedo);                           // adding, Eq 10
-        sA[64L * s] = Tdif * denom;
-        sB[64L * s] = Rdif * denom;
-        sC[64L * s] = Tdir * denom;
-        sTn[64L * s] = Tnoscat;
+        const double ctau = ptau[0], cssa = pssa[0], cg = pg[0];
+#pragma unroll
+        for (int d = 0; d + 1 < kPF; ++d) { ptau[d] = ptau[d + 1]; pssa[d] = pssa[d + 1]; pg[d] = pg[d + 1]; }
+        {
+          const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
+          ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
+        }
+        const TwoStream ts = two_stream(ctau, cssa, cg, mu0, mu0_inv);
+        const double denom = 1. / (1. - ts.Rdif * albedo);                           // adding, Eq 10
+        if (!RECOMPUTE) {
+          sA[64L * s] = ts.Tdif * denom;
+          sB[64L * s] = ts.Rdif * denom;
+          sC[64L * s] = ts.Tdir * denom;
+          sTn[64L * s] = ts.Tnoscat;
+        }
         // Eq 11 divided by F_dir(l): src_up = Rdir*F_dir(l), src_dn = Tdir*F_dir(l), src(l+1) = nsrc*Tnoscat*F_dir(l)
-        nsrc = Rdir + Tdif * denom * (nsrc * Tnoscat + albedo * Tdir);
-        albedo = Rdif + Tdif * Tdif * albedo * denom;                              // Eq 9
+        nsrc = ts.Rdir + ts.Tdif * denom * (nsrc * ts.Tnoscat + albedo * ts.Tdir);
+        albedo = ts.Rdif + ts.Tdif * ts.Tdif * albedo * denom;                        // Eq 9
         sAlb[64L * s] = albedo;
         sSrc[64L * s] = nsrc;
       }
@@ -132,11 +171,44 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
         acc_add(&acc_dn[cl], vd, owner);
         acc_add(&acc_dir[cl], vr, owner);
       }
+      double palb[kPF], pnsrc[kPF];
+#pragma unroll
+      for (int d = 0; d < kPF; ++d) {
+        const int sl = d < nlay ? d : nlay - 1;
+        palb[d] = sAlb[64L * (sl + 1)]; pnsrc[d] = sSrc[64L * (sl + 1)];
+        if (RECOMPUTE) {
+          const long q = base + (long)ncol * (lay0 + lstep * sl);
+          ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
+        }
+      }
       for (int s = 0; s < nlay; ++s) {
-        const double fdir_next = sTn[64L * s] * fdir;
-        const double src_next = sSrc[64L * (s + 1)] * fdir_next;
-        fdn = sA[64L * s] * fdn + sB[64L * s] * src_next + sC[64L * s] * fdir;
-        const double fup = fdn * sAlb[64L * (s + 1)] + src_next;
+        const double alb_next = palb[0], nsrc_next = pnsrc[0];
+        const double ctau = ptau[0], cssa = pssa[0], cg = pg[0];
+#pragma unroll
+        for (int d = 0; d + 1 < kPF; ++d) {
+          palb[d] = palb[d + 1]; pnsrc[d] = pnsrc[d + 1];
+          ptau[d] = ptau[d + 1]; pssa[d] = pssa[d + 1]; pg[d] = pg[d + 1];
+        }
+        {
+          const int sn = s + kPF < nlay ? s + kPF : nlay - 1;
+          palb[kPF - 1] = sAlb[64L * (sn + 1)]; pnsrc[kPF - 1] = sSrc[64L * (sn + 1)];
+          if (RECOMPUTE) {
+            const long q = base + (long)ncol * (lay0 + lstep * sn);
+            ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
+          }
+        }
+        double A, B, C, Tn;
+        if (RECOMPUTE) {
+          const TwoStream ts = two_stream(ctau, cssa, cg, mu0, mu0_inv);
+          const double denom = 1. / (1. - ts.Rdif * alb_next);   // the same expression as in pass 1: same bits
+          A = ts.Tdif * denom; B = ts.Rdif * denom; C = ts.Tdir * denom; Tn = ts.Tnoscat;
+        } else {
+          A = sA[64L * s]; B = sB[64L * s]; C = sC[64L * s]; Tn = sTn[64L * s];
+        }
+        const double fdir_next = Tn * fdir;
+        const double src_next = nsrc_next * fdir_next;
+        fdn = A * fdn + B * src_next + C * fdir;
+        const double fup = fdn * alb_next + src_next;
         fdir = fdir_next;
         const double vu = gsum<CW>(keep * fup), vd = gsum<CW>(keep * (fdn + fdir)), vr = gsum<CW>(keep * fdir);
         acc_add(&acc_up[(s + 1) * CW + cl], vu, owner);
@@ -168,13 +240,13 @@ size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
   (void)ng;
   long tiles = ((long)ncol + ECCKD_SW_CW - 1) / ECCKD_SW_CW;
   if (tiles > kSwWaves) tiles = kSwWaves;
-  return sizeof(double) * (size_t)(4L * nlay + 2L * (nlay + 1)) * 64 * (size_t)tiles;
+  return sizeof(double) * (size_t)((kSwRecompute ? 0L : 4L) * nlay + 2L * (nlay + 1)) * 64 * (size_t)tiles;
 }
 
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   constexpr int CW = ECCKD_SW_CW;
-  auto k = rte_sw_kernel<CW>;
+  auto k = rte_sw_kernel<CW, kSwRecompute>;
   const size_t lds = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
