@@ -257,6 +257,13 @@ int check_dims(int ncol, int nlay) {
   if (ncol < 0 || nlay < 1) return fail("ecckd: bad ncol/nlay");
   return 0;
 }
+int check_gas_optics_dims(int ncol, int nlay) {
+  if (check_dims(ncol, nlay)) return 1;
+  // the gas-optics kernels address one g-plane pair of a column-fastest array with 32-bit byte offsets
+  if (((size_t)ncol * (size_t)nlay + (size_t)ncol) * sizeof(double) >= (size_t)0xFFFFFFF0u)
+    return fail("ecckd: ncol*(nlay+1) too large for one call (limit 2^29 elements): split the column range");
+  return 0;
+}
 
 // Copies gas_desc data arrays to the arena and returns the device-side description.
 struct StagedGases {
@@ -592,7 +599,7 @@ int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double
                         const double *vmr_scalar, double *tau, double *lay_source,
                         double *lev_source_inc, double *lev_source_dec, double *sfc_source,
                         int memspace, void *stream) {
-  if (check_model(m) || check_dims(ncol, nlay)) return 1;
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
   if (!m->has_planck) return fail("ecckd_gas_optics_lw: model has no Planck table (shortwave model?)");
   if (!plev || !tlay || !tsfc || !tau || !lay_source || !sfc_source || (ngas > 0 && !gas_names))
     return fail("ecckd_gas_optics_lw: null argument");
@@ -671,7 +678,7 @@ int ecckd_gas_optics_sw(const ecckd_model_t *m, int ncol, int nlay, const double
                         const double *const *vmr, const long long *vmr_col_stride,
                         const long long *vmr_lay_stride, const double *vmr_scalar, double *tau,
                         double *ssa, double *g, double *toa_src, int memspace, void *stream) {
-  if (check_model(m) || check_dims(ncol, nlay)) return 1;
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
   if (!m->has_solar) return fail("ecckd_gas_optics_sw: model has no solar table (longwave model?)");
   if (!plev || !tlay || !tau || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_sw: null argument");
   const bool two_stream = ssa && g;

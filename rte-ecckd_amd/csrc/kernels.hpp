@@ -52,12 +52,15 @@ struct UDiv { double d, r; int exact; };
 
 // Per-slot view of the gases of a pass for the fused kernel: slot s < nbil is the s-th bilinear
 // gas, slot kTauPassGases is the look_up_table gas.  `vmr` is ALWAYS a valid device address (the
-// load is issued unconditionally, all slots in one round); `use_scalar` picks `scalar` afterwards.
+// load is issued unconditionally, all slots in one round).  The mole fraction that enters the
+// weight is fma(alpha, loaded, beta) with alpha in {0, 1}, which spells every case of
+// src/gas_optics_ecckd.f90:143-149 exactly: array/linear (1, 0); array/relative_linear (1, -ref);
+// scalar/linear (0, scalar); scalar/relative_linear (0, scalar - ref); none_ (0, 1); unused (0, 0).
 struct SlotArgs {
   const double *vmr;
-  long long cs, ls;
-  double scalar, ref;
-  int use_scalar, code;
+  long long ls;                // layer stride, elements
+  unsigned cs_bytes;           // column stride, bytes (32-bit: checked on the host)
+  double alpha, beta;
 };
 
 // Fused gas-optics launch (kernels_gas_fused.hip): the tau arguments plus the Planck side.

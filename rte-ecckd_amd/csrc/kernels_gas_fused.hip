@@ -166,23 +166,26 @@ __device__ __forceinline__ float swap_adjacent(float x) {
 // per-g-point path), so the store is unconditional -- no exec mask, no skip branch, and the
 // compiler's vmcnt bookkeeping stays exact across a tile (a load may wait for "all but the last 16
 // stores" instead of "every store").
-//   base: wave-uniform pointer to (column 0, plane g); voff: per-lane BYTE offset
-//   sizeof(real) * ((c - odd) + (odd ? plane : 0)), 32 bits; the four output arrays share it.
+//   base: wave-uniform RUNNING pointer to (column 0, plane g) of the array, advanced by two planes
+//   (plane2 elements) after the store -- the g-pairs of an array are stored in ascending order, so
+//   one pointer per array walks the whole tile and nothing per (array, g-pair) is loop invariant;
+//   voff: per-lane BYTE offset sizeof(real) * ((c - odd) + (odd ? plane : 0)), 32 bits, shared by
+//   the four output arrays.
 template <typename real>
-__device__ __forceinline__ void store_pair(real *base, unsigned voff, real v0, real v1, bool odd) {
+__device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned voff, real v0, real v1, bool odd) {
   typedef real double2_t __attribute__((ext_vector_type(2)));
   const real recv = swap_adjacent(odd ? v0 : v1);
   double2_t out;
   out[0] = odd ? recv : v0;
   out[1] = odd ? v1 : recv;
+  // Pin the pointer in SGPRs right here: left alone, the optimiser precomputes one pointer per
+  // (array, g-pair) outside the loops (32 SGPRs, spilled to VGPR lanes and read back per store) or
+  // hoists the per-lane sum array + voff (32 VGPRs).
+  asm volatile("" : "+s"(base));
 #ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
-  // Pin the plane pointer in SGPRs right here: left alone, the optimiser hoists the per-lane sum
-  // array + voff out of the loops (one 64-bit VGPR pair per array and g-pair) and adds the
-  // uniform part per store.
-  typedef __attribute__((address_space(1))) char gchar;          // global, not flat: the pin below
+  typedef __attribute__((address_space(1))) char gchar;          // global, not flat: the pin
   typedef __attribute__((address_space(1))) double2_t gdouble2;  // hides the pointer's origin
   gchar *gbase = (gchar *)base;
-  asm volatile("" : "+s"(gbase));
 #ifndef ECCKD_PLAIN_STORES   // nontemporal: the outputs are written once and read by the next kernel
   __builtin_nontemporal_store(out, reinterpret_cast<gdouble2 *>(gbase + voff));
 #else
@@ -191,6 +194,7 @@ __device__ __forceinline__ void store_pair(real *base, unsigned voff, real v0, r
 #else
   asm volatile("" :: "v"(out));
 #endif
+  base += plane2;
 }
 
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
@@ -227,6 +231,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   __syncthreads();
   for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = P(t.temperature)[i];
   int pw_lo = -1;   // first table row of the staged Planck window (-1: nothing staged yet)
+  // per-column inputs: wave-uniform row pointers (this block's layer) + 32-bit per-lane byte offsets
+  typedef __attribute__((address_space(1))) const char gcchar_t;
+  typedef __attribute__((address_space(1))) const real greal_t;
+  gcchar_t *slot_base[NB + 1];
+  unsigned slot_cs[NB + 1];
+#pragma unroll
+  for (int s = 0; s <= NB; ++s) {
+    const SlotArgs &e = a.slot[s < NB ? s : kTauPassGases];
+    slot_base[s] = (gcchar_t *)(P(e.vmr) + (long)j * e.ls);
+    slot_cs[s] = e.cs_bytes;
+  }
 
   const long ntiles = ((long)ncol + kBlock - 1) / kBlock;
   const long t_begin = ntiles * blockIdx.x / gridDim.x;
@@ -338,15 +353,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     real nx_p0, nx_p1, nx_T, nx_W[NB], nx_vlut, nx_Tl0 = real(0), nx_Tl1 = real(0);
     auto load_inputs = [&](long tile) {
       const long c = tile * kBlock + tid;
-      const long cc = c < ncol ? c : (long)ncol - 1;
-      nx_p0 = plev0[cc]; nx_p1 = plev1[cc];
-      nx_T = P(t.tlay)[cc + (long)ncol * j];
+      const unsigned cc32 = (unsigned)(c < ncol ? c : (long)ncol - 1);
+      const unsigned co = cc32 * (unsigned)sizeof(real);
+      auto at = [&](const real *row) { return *reinterpret_cast<greal_t *>((gcchar_t *)row + co); };
+      nx_p0 = at(plev0); nx_p1 = at(plev1);
+      nx_T = at(P(t.tlay) + (long)ncol * j);
 #pragma unroll
-      for (int s = 0; s < NB; ++s) nx_W[s] = P(a.slot[s].vmr)[cc * a.slot[s].cs + j * a.slot[s].ls];
-      nx_vlut = P(a.slot[kTauPassGases].vmr)[cc * a.slot[kTauPassGases].cs + j * a.slot[kTauPassGases].ls];
+      for (int s = 0; s < NB; ++s) nx_W[s] = *reinterpret_cast<greal_t *>(slot_base[s] + cc32 * slot_cs[s]);
+      nx_vlut = *reinterpret_cast<greal_t *>(slot_base[NB] + cc32 * slot_cs[NB]);
       if (MODE == MODE_LW && a.tlev) {
-        nx_Tl0 = P(a.tlev)[cc + (long)ncol * j];
-        nx_Tl1 = P(a.tlev)[cc + (long)ncol * (j + 1)];
+        nx_Tl0 = at(P(a.tlev) + (long)ncol * j);
+        nx_Tl1 = at(P(a.tlev) + (long)ncol * (j + 1));
       }
     };
 #ifndef ECCKD_FUSED_NO_PREFETCH
@@ -395,7 +412,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       int iv0 = 1;
       if (t.lut >= 0) {   // :153-163
         const SeqGas &e = t.seq[t.lut];
-        vlut = a.slot[kTauPassGases].use_scalar ? (real)a.slot[kTauPassGases].scalar : vlut;
+        vlut = fma((real)a.slot[kTauPassGases].alpha, vlut, (real)a.slot[kTauPassGases].beta);
         const real log_vmr = log(selmax(vlut, (real)e.mf0));
         real vmr_index = udiv(log_vmr - (real)e.log_mf0, ud_dlv);
         vmr_index = real(1) + selmax(real(0), selmin(vmr_index, (real)e.nv - real(1.001)));
@@ -411,10 +428,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
       for (int s = 0; s < NB; ++s) {
         const SlotArgs &e = a.slot[s];
-        const real v = e.use_scalar ? (real)e.scalar : W[s];
-        real x = e.code == 3 ? simple_weight * (v - (real)e.ref) : (e.code == 0 ? simple_weight : simple_weight * v);
+        real x = simple_weight * fma((real)e.alpha, W[s], (real)e.beta);   // :143-149, see SlotArgs
         if (!ANYCLAMP) x = x < real(0) ? real(0) : x;   // od<0 -> 0 (:234-238) == weight<0 -> 0 for tables >= 0
-        W[s] = s < t.nbil ? x : real(0);
+        W[s] = x;
       }
       PlPoint<real> qlay{0, 0, real(0), real(0)}, ql0{0, 0, real(0), real(0)}, ql1{0, 0, real(0), real(0)};
       bool inwin = true;
@@ -431,6 +447,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const real moles = dp * gw;   // :313-314 (SW)
       // ragged waves (end of the column range) and waves outside the staged rows go the slow way
       const bool fast = __all(inslab && pair_ok && inwin);
+      const int ip0_ = ip0, it0_ = it0, iv0_ = iv0;
 #ifndef ECCKD_FUSED_NO_PREFETCH
       load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
 #endif
@@ -460,6 +477,13 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         const unsigned plane = (unsigned)ncol * (unsigned)nlay;
         const unsigned coff = (unsigned)sizeof(real) * (unsigned)cc;
         const unsigned voff = (unsigned)sizeof(real) * ((unsigned)(c - (odd ? 1 : 0)) + (odd ? plane : 0u));
+        // running output pointers: (column 0, layer j, g-point 0), advanced by store_pair
+        const long plane2 = 2L * plane;
+        real *w_tau = Q(t.tau) + (long)ncol * j, *w_ssa = MODE == MODE_SW && t.ssa ? Q(t.ssa) + (long)ncol * j : nullptr;
+        real *w_g = MODE == MODE_SW && t.ssa ? Q(t.g) + (long)ncol * j : nullptr;
+        real *w_lay = MODE == MODE_LW ? Q(a.lay_source) + (long)ncol * j : nullptr;
+        real *w_dec = MODE == MODE_LW && a.tlev ? Q(a.lev_source_dec) + (long)ncol * j : nullptr;
+        real *w_inc = MODE == MODE_LW && a.tlev ? Q(a.lev_source_inc) + (long)ncol * j : nullptr;
         for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
           real acc[GC];
           if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
@@ -545,17 +569,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int g = 0; g < GC; g += 2) {
                     if (FULL || gb + g + 1 < ng) {
-                      const long og = oj + (long)plane * g;
+                      (void)oj;
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair<real>(Q(t.tau) + og, voff, t0_, t1_, odd);
+                        store_pair<real>(w_tau, plane2, voff, t0_, t1_, odd);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair<real>(Q(t.ssa) + og, voff, r0 / t0_, r1 / t1_, odd);
-                          store_pair<real>(Q(t.g) + og, voff, real(0), real(0), odd);
+                          store_pair<real>(w_ssa, plane2, voff, r0 / t0_, r1 / t1_, odd);
+                          store_pair<real>(w_g, plane2, voff, real(0), real(0), odd);
                         }
                       } else {
-                        store_pair<real>(Q(t.tau) + og, voff, acc[g], acc[g + 1], odd);
+                        store_pair<real>(w_tau, plane2, voff, acc[g], acc[g + 1], odd);
                       }
                     } else if (gb + g < ng) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
@@ -573,7 +597,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
               } else {
                 const int k = pi_ - NLI - NBI, g = 2 * (k / 2);
                 const bool both = FULL || gb + g + 1 < ng;
-                const long og = oj + (long)plane * g;
+                (void)oj;
                 const long o1 = c + (long)ncol * (j + (long)nlay * (gb + g));   // odd ng: last g-point alone
                 if ((k & 1) == 0) {
                   real vl[2], v0[2];
@@ -583,8 +607,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                     v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
                   }
                   if (both) {
-                    store_pair<real>(Q(a.lay_source) + og, voff, vl[0], vl[1], odd);
-                    if (a.tlev) store_pair<real>(Q(a.lev_source_dec) + og, voff, v0[0], v0[1], odd);   // :423
+                    store_pair<real>(w_lay, plane2, voff, vl[0], vl[1], odd);
+                    if (a.tlev) store_pair<real>(w_dec, plane2, voff, v0[0], v0[1], odd);   // :423
                   } else if (gb + g < ng) {
                     Q(a.lay_source)[o1] = vl[0];
                     if (a.tlev) Q(a.lev_source_dec)[o1] = v0[0];
@@ -594,7 +618,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int q = 0; q < 2; ++q) v1[q] = div_pi(ql1.w0 * b[0][q] + ql1.w1 * b[1][q], pi, rpi);
                   if (a.tlev) {                                                      // :424
-                    if (both) store_pair<real>(Q(a.lev_source_inc) + og, voff, v1[0], v1[1], odd);
+                    if (both) store_pair<real>(w_inc, plane2, voff, v1[0], v1[1], odd);
                     else if (gb + g < ng) Q(a.lev_source_inc)[o1] = v1[0];
                   }
                 }
@@ -604,6 +628,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         }
       } else {
         // ---- a lane of this wave is outside the staged rows: tables from global memory ----
+        // (the indices go through an opaque asm: otherwise the 64-bit address arithmetic of this
+        // rare path is speculated above the branch and paid by every tile)
+        int ip0 = ip0_, it0 = it0_, iv0 = iv0_;
+        asm volatile("" : "+v"(ip0), "+v"(it0), "+v"(iv0));
         for (int g = 0; g < ng; ++g) {
           const long o = cc + (long)ncol * (j + (long)nlay * g);
           real acc = t.accumulate ? P(t.tau)[o] : real(0);
@@ -765,14 +793,26 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   a.ud_dt = make_udiv(t.dt, a.f32);
   a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1., a.f32);
   a.ud_pdt = make_udiv(a.mode == MODE_LW ? a.pdt : 1., a.f32);
+  const size_t esz = a.f32 ? sizeof(float) : sizeof(double);
+  // working-precision arithmetic for the constants folded on the host
+  auto sub = [&](double x, double y) { return a.f32 ? (double)((float)x - (float)y) : x - y; };
   for (int s = 0; s <= kTauPassGases; ++s) {
     const int k = s < kTauPassGases ? (s < t.nbil ? t.bil_seq[s] : -1) : t.lut;
     SlotArgs &o = a.slot[s];
-    o = SlotArgs{t.plev, 0, 0, 0., 0., 1, 1};   // unused slot: a harmless load, weight forced to 0
+    o = SlotArgs{t.plev, 0, 0u, 0., 0.};   // unused slot: a harmless load, weight 0
     if (k >= 0) {
       const SeqGas &e = t.seq[k];
-      o.scalar = e.scalar; o.ref = e.ref; o.code = e.code;
-      if (e.vmr) { o.vmr = e.vmr; o.cs = e.cs; o.ls = e.ls; o.use_scalar = 0; }
+      const bool arr = e.vmr != nullptr;
+      if (arr) {
+        if (e.cs < 0 || (unsigned long long)e.cs * (unsigned long long)(t.ncol > 0 ? t.ncol : 1) * esz >= 0xFFFFFFF0ull)
+          return hipErrorInvalidValue;   // column stride of a vmr array beyond 32-bit byte offsets
+        o.vmr = e.vmr; o.ls = e.ls; o.cs_bytes = (unsigned)((unsigned long long)e.cs * esz);
+      }
+      switch (e.code) {
+        case 0: o.alpha = 0.; o.beta = 1.; break;                                     // none_: weight = simple_weight (:213-221)
+        case 3: o.alpha = arr ? 1. : 0.; o.beta = arr ? -e.ref : sub(e.scalar, e.ref); break;   // relative_linear (:146)
+        default: o.alpha = arr ? 1. : 0.; o.beta = arr ? 0. : e.scalar; break;        // linear, look_up_table (:148)
+      }
     }
   }
   if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;

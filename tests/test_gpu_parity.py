@@ -106,6 +106,21 @@ def test_host_and_device_memspace_agree(pkg, gpu, lw):
         assert np.array_equal(a, b)
 
 
+def test_column_count_limit_is_an_error_not_a_fault(pkg, gpu, lw):
+    """The gas-optics kernels address a g-plane pair with 32-bit byte offsets: a call whose
+    ncol*(nlay+1) does not fit is refused before anything is read (no reference counterpart)."""
+    import ctypes as C
+    k, _ = lw
+    d = np.zeros(8)
+    p = d.ctypes.data_as(C.c_void_p)
+    none = (C.c_void_p * 1)()
+    z = (C.c_longlong * 1)(0)
+    sc = (C.c_double * 1)(0.0)
+    rc = pkg.lib().ecckd_gas_optics_lw(k._need(), 9_000_000, 60, p, p, p, p, 0, b"", none, z, z, sc, p, p, p, p, p,
+                                       pkg.HOST, None)
+    assert rc != 0 and "split the column range" in pkg.last_error()
+
+
 def test_tlev_required_error_behaviour(pkg, gpu, oracle_mod, lw):
     """:414-417 -- tau, lay_source and sfc_source are produced, then the call fails."""
     k, m = lw
