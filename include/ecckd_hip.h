@@ -188,6 +188,21 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  int memspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Launch plan of a gas_optics call (no counterpart in the reference; works on host-only models,
+ * device -1, and launches nothing): how the library would run gas_optics for this model, gas list
+ * (names only; LW if the model has a Planck table, else SW), size, precision and the current
+ * arithmetic mode.
+ *   plan[0] kernel passes over the gas list (<= 10 gases and one look_up_table gas per pass)
+ *   plan[1] 1: first pass is the fused kernel, 0: reference-order tau kernel
+ *   plan[2] 1: the Planck sources ride in that pass (LW), 0: separate Planck kernel / SW
+ *   plan[3] pressure rows of the LDS slab      plan[4] Planck-table rows staged in LDS (ntp = whole table)
+ *   plan[5] column chunks (grid.x)             plan[6] LDS bytes per block
+ *   plan[7] g-points per chunk of the item pipeline
+ * --------------------------------------------------------------------------------------- */
+int ecckd_gas_optics_plan(const ecckd_model_t *model, int ncol, int nlay, int single_precision,
+                          int ngas, const char *gas_names, int *plan);
+
+/* ---------------------------------------------------------------------------------------
  * Arithmetic mode of gas_optics (process-wide).
  *   0 (default) fast: one fused kernel per call; the interpolation weights of a cell are
  *               multiplied out once and each coefficient costs one FMA.  Same formula as

@@ -132,6 +132,7 @@ def lib():
     L.ecckd_model_destroy.restype = None
     L.ecckd_model_add_gas.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_double, C.c_void_p]
+    L.ecckd_gas_optics_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
     _lib = L
     return L
 
@@ -448,6 +449,18 @@ class GasOpticsEcckd:
 
     def source_is_external(self):
         return bool(lib().ecckd_model_source_is_external(self._need()))
+
+    def plan(self, ncol, nlay, gas_names, single_precision=False):
+        """``ecckd_gas_optics_plan``: how gas_optics would run for this model, gas list and size (works
+        without a GPU on a ``device=-1`` model).  Returns a dict, or raises RuntimeError with the
+        library's message."""
+        names = b"".join(n.strip().lower().encode().ljust(NAME_LEN, b" ") for n in gas_names)
+        out = (C.c_int * 8)()
+        if lib().ecckd_gas_optics_plan(self._need(), int(ncol), int(nlay), int(bool(single_precision)),
+                                       len(gas_names), names, out):
+            raise RuntimeError(last_error())
+        keys = ("passes", "fused", "planck_fused", "slab_rows", "planck_rows", "col_chunks", "lds_bytes", "g_chunk")
+        return dict(zip(keys, list(out)))
 
     def get_press_min(self):
         return lib().ecckd_model_get_press_min(self._need())

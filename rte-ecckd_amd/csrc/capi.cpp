@@ -66,6 +66,12 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // helper below sizes its copies with esz() and the kernels are launched with f32 = 1.  Data pointers
 // keep their `double *` static type on the way through (they are only passed on, never indexed).
 thread_local int g_f32 = 0;
+// ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
+struct PlanRecord {
+  int npass = 0, first_fused = 0, planck_fused = 0;
+  ecckd::FusedPlan first;
+};
+thread_local PlanRecord *g_plan = nullptr;
 size_t esz() { return g_f32 ? sizeof(float) : sizeof(double); }
 struct F32Scope {
   F32Scope() { g_f32 = 1; }
@@ -234,12 +240,23 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
       if (g_f32 && (fa.mode != 1 || !last))
         return fail("ecckd: single precision is implemented for the fused longwave gas optics only (this model/"
                     "gas list needs the multi-pass or unfused path)");
-      ProfScope prof(fa.mode == 1 ? (g_f32 ? "gas_lw_fused_f32" : "gas_lw_fused") : "tau", stream);
-      HIPCHK(launch_gas_fused(fa, stream));
+      if (g_plan) {
+        FusedPlan fp;
+        HIPCHK(prepare_gas_fused(fa, fp));
+        if (g_plan->npass == 0) { g_plan->first_fused = 1; g_plan->planck_fused = fa.mode == 1; g_plan->first = fp; }
+        ++g_plan->npass;
+      } else {
+        ProfScope prof(fa.mode == 1 ? (g_f32 ? "gas_lw_fused_f32" : "gas_lw_fused") : "tau", stream);
+        HIPCHK(launch_gas_fused(fa, stream));
+      }
     } else {
       if (g_f32) return fail("ecckd: single precision needs the fast arithmetic mode (ecckd_set_arithmetic(0))");
-      ProfScope prof("tau", stream);
-      HIPCHK(launch_tau(a, stream));
+      if (g_plan) {
+        ++g_plan->npass;
+      } else {
+        ProfScope prof("tau", stream);
+        HIPCHK(launch_tau(a, stream));
+      }
     }
     first_pass = false;
   } while (pos < seq.size());
@@ -589,6 +606,35 @@ static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const dou
     ProfScope prof("planck", stream);
     HIPCHK(ecckd::launch_planck(p, stream));                        // :407-424
   }
+  return 0;
+}
+
+int ecckd_gas_optics_plan(const ecckd_model_t *m, int ncol, int nlay, int single_precision, int ngas,
+                          const char *gas_names, int *plan) {
+  if (!m) return fail("ecckd: null model");
+  if (!m->finalized) return fail("ecckd: model is not finalized");
+  if (check_gas_optics_dims(ncol, nlay)) return 1;
+  if (!plan || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_plan: null argument");
+  PlanRecord rec;
+  const GasDesc gd{ngas, gas_names, nullptr, nullptr, nullptr, nullptr};
+  const PlanckSide pl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const bool lw = m->has_planck;
+  struct Guard {
+    explicit Guard(PlanRecord *r, int f32) { g_plan = r; g_f32 = f32; }
+    ~Guard() { g_plan = nullptr; g_f32 = 0; }
+  } guard(&rec, single_precision ? 1 : 0);
+  bool planck_done = false;
+  if (gas_optical_depth_dev(m, ncol, nlay, nullptr, nullptr, gd, nullptr, !lw, nullptr, nullptr, lw ? &pl : nullptr,
+                            &planck_done, nullptr))
+    return 1;
+  plan[0] = rec.npass;
+  plan[1] = rec.first_fused;
+  plan[2] = rec.planck_fused;
+  plan[3] = rec.first.slab_rows;
+  plan[4] = rec.first.planck_rows;
+  plan[5] = rec.first.col_chunks;
+  plan[6] = (int)rec.first.lds_bytes;
+  plan[7] = rec.first.GC;
   return 0;
 }
 

@@ -116,6 +116,14 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
+// What prepare_gas_fused() decided for one pass.
+struct FusedPlan {
+  int empty = 0;               // ncol == 0: nothing to launch
+  size_t lds_bytes = 0;
+  int anyclamp = 0, GC = 0, NB = 0;
+  int slab_rows = 0, planck_rows = 0, col_chunks = 0;
+};
+hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan);
 int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32);
 int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int anyclamp, int f32);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);

@@ -504,7 +504,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
             for (int g = 0; g < GC; ++g) acc[g] = real(0);
           }
           const int pb = L.pl + gb;
-          const long oj = (long)ncol * (j + (long)nlay * gb);   // (column 0, layer j, g-point gb)
           double2_t buf[2][4];
           real lutp[2] = {real(0), real(0)};
           static_for<0, NIT + 1>([&](auto it_c) __attribute__((always_inline)) {
@@ -569,7 +568,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int g = 0; g < GC; g += 2) {
                     if (FULL || gb + g + 1 < ng) {
-                      (void)oj;
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
@@ -597,7 +595,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
               } else {
                 const int k = pi_ - NLI - NBI, g = 2 * (k / 2);
                 const bool both = FULL || gb + g + 1 < ng;
-                (void)oj;
                 const long o1 = c + (long)ncol * (j + (long)nlay * (gb + g));   // odd ng: last g-point alone
                 if ((k & 1) == 0) {
                   real vl[2], v0[2];
@@ -787,8 +784,11 @@ UDiv make_udiv(double d, int f32) {
   return u;
 }
 
-hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
+// Host-side decisions of a fused launch (slots, slab rows, Planck window, grid): everything but the
+// launch itself, so that ecckd_gas_optics_plan() can report them without a GPU.
+hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   TauArgs &t = a.tau;
+  plan = FusedPlan{};
   a.ud_dlp = make_udiv(t.dlp, a.f32);
   a.ud_dt = make_udiv(t.dt, a.f32);
   a.ud_dlv = make_udiv(t.lut >= 0 ? t.seq[t.lut].d_log_vmr : 1., a.f32);
@@ -815,7 +815,7 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
       }
     }
   }
-  if (t.ncol <= 0 || t.nlay <= 0) return hipSuccess;
+  if (t.ncol <= 0 || t.nlay <= 0) { plan.empty = 1; return hipSuccess; }
   if (t.nseq > kTauPassGases) return hipErrorInvalidValue;
   // store_pair() addresses a plane pair with a 32-bit byte offset
   if (((size_t)t.ncol * (size_t)t.nlay + (size_t)t.ncol) * (a.f32 ? sizeof(float) : sizeof(double)) >= (size_t)0xFFFFFFF0u)
@@ -844,13 +844,24 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   if (chunks * kSeg > ntiles) chunks = (ntiles + kSeg - 1) / kSeg;
   if (chunks < 1) chunks = 1;
   t.col_chunks = (int)chunks;
-  if (a.f32) {   // single precision: the longwave fused path only
-    if (a.mode != MODE_LW) return hipErrorNotSupported;
-    return launch_mode<float, MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
-  }
-  if (a.mode == MODE_LW) return launch_mode<double, MODE_LW>(a, lds, pick_nb(t.nbil), anyclamp, s);
-  if (a.mode == MODE_SW) return launch_mode<double, MODE_SW>(a, lds, pick_nb(t.nbil), anyclamp, s);
-  return launch_mode<double, MODE_TAU>(a, lds, pick_nb(t.nbil), anyclamp, s);
+  if (a.f32 && a.mode != MODE_LW) return hipErrorNotSupported;   // single precision: the longwave fused path only
+  plan.lds_bytes = lds;
+  plan.anyclamp = anyclamp ? 1 : 0;
+  plan.GC = GC; plan.NB = NB;
+  plan.slab_rows = t.R; plan.planck_rows = a.pw; plan.col_chunks = t.col_chunks;
+  return hipSuccess;
+}
+
+hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
+  FusedPlan plan;
+  const hipError_t e = prepare_gas_fused(a, plan);
+  if (e != hipSuccess || plan.empty) return e;
+  const TauArgs &t = a.tau;
+  const bool anyclamp = plan.anyclamp != 0;
+  if (a.f32) return launch_mode<float, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
+  if (a.mode == MODE_LW) return launch_mode<double, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
+  if (a.mode == MODE_SW) return launch_mode<double, MODE_SW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
+  return launch_mode<double, MODE_TAU>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
 }
 
 }  // namespace ecckd

@@ -9,6 +9,7 @@ import pytest
 
 import __graft_entry__ as entry
 from conftest import LW_FSCK, LW_RRTMGP, SW_WIDE
+from rte_ecckd_amd import synthetic
 
 
 def test_library_exports_every_declared_symbol(pkg):
@@ -104,6 +105,59 @@ def test_no_gpu_means_error_not_fallback(pkg):
     assert np.all(op.tau == -7.0)             # untouched: nothing was computed anywhere
     fl = pkg.FluxesBroadband(np.zeros((nlay + 1, ncol)), np.zeros((nlay + 1, ncol)))
     assert "no HIP device" in pkg.rte_lw(op, True, src, np.ones((ncol, 1)), fl)
+
+
+def test_launch_plan_host_logic(pkg, oracle_mod, monkeypatch):
+    """ecckd_gas_optics_plan: the host-side decisions of gas_optics (fused or not, slab rows, Planck
+    window, pass splitting, grid) on host-only models -- no GPU, nothing launched."""
+    gases = synthetic.GAS_ORDER
+    k32 = pkg.GasOpticsEcckd(); assert k32.load(LW_FSCK, device=-1) == ""
+    p = k32.plan(1000000, 60, gases)
+    assert p["passes"] == 1 and p["fused"] == 1 and p["planck_fused"] == 1
+    assert p["planck_rows"] == 231                      # whole Planck table next to the slab
+    assert p["slab_rows"] >= 3 and p["lds_bytes"] <= 160 * 1024 and p["g_chunk"] == 8
+    assert (p["col_chunks"] * 60) % 256 == 0            # full rounds of the 256 CUs
+    small = k32.plan(100, 60, gases)
+    assert small["col_chunks"] == 1
+    # fp32 halves the table bytes: more pressure rows fit
+    assert k32.plan(1000000, 60, gases, single_precision=True)["slab_rows"] > p["slab_rows"]
+    # the 36-g file: the whole table does not fit next to 3 rows -> a window of it
+    k36 = pkg.GasOpticsEcckd(); assert k36.load(LW_RRTMGP, device=-1) == ""
+    q = k36.plan(1000000, 60, gases)
+    assert q["fused"] == 1 and q["planck_fused"] == 1 and 16 <= q["planck_rows"] < 231 and q["slab_rows"] >= 3
+    assert q["g_chunk"] == 4                            # 36 is a multiple of 4, not of 8
+    monkeypatch.setenv("ECCKD_PLANCK_WINDOW", "16")
+    assert k32.plan(1000, 60, gases)["planck_rows"] == 16
+    monkeypatch.delenv("ECCKD_PLANCK_WINDOW")
+    # shortwave: fused tau + Rayleigh epilogue, no Planck
+    ksw = pkg.GasOpticsEcckd(); assert ksw.load(SW_WIDE, device=-1) == ""
+    r = ksw.plan(100000, 60, gases)
+    assert r["fused"] == 1 and r["planck_fused"] == 0 and r["planck_rows"] == 0 and r["g_chunk"] == 4
+    # reference-order arithmetic: the per-gas kernels, nothing fused; single precision is refused there
+    pkg.set_arithmetic(pkg.REFERENCE_ORDER)
+    try:
+        assert k32.plan(1000, 60, gases)["fused"] == 0
+        with pytest.raises(RuntimeError, match="single precision"):
+            k32.plan(1000, 60, gases, single_precision=True)
+    finally:
+        pkg.set_arithmetic(pkg.FAST)
+    # unknown gases are skipped, an empty list is still one (empty) pass; oversize calls are refused
+    assert k32.plan(1000, 60, ["no2", "xyz"])["passes"] == 1
+    with pytest.raises(RuntimeError, match="split the column range"):
+        k32.plan(9_000_000, 60, gases)
+    # two look_up_table gases cannot share a pass
+    m = oracle_mod.CkdModel(LW_FSCK)
+    tabs = [dict(name=n, code=t["code"], composite_only=0, mole_fraction=t["mole_fraction"],
+                 reference_mole_fraction=t["reference_mole_fraction"],
+                 coefficient=t["coefficient"] if t["code"] == 2 else t["coefficient"][0])
+            for n, t in zip(m.gas[:3], m.tables[:3])]
+    tabs.append(dict(name="h2o_b", code=2, composite_only=0, mole_fraction=m.tables[0]["mole_fraction"] * 0.5,
+                     reference_mole_fraction=0.0, coefficient=m.tables[0]["coefficient"] * 0.25))
+    k2 = pkg.GasOpticsEcckd()
+    assert k2.init_from_tables(m.log_pressure, m.temperature, tabs,
+                               planck=(m.temperature_planck, m.planck_function), device=-1) == ""
+    two = k2.plan(5000, 60, [t["name"] for t in tabs])
+    assert two["passes"] == 2 and two["planck_fused"] == 1
 
 
 def test_gas_concs_mirror(pkg):
