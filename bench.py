@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncol", type=int, default=1000000, help="synthetic columns per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--host-sample", type=int, default=20000,
+                    help="columns of the PCIe-inclusive side measurement through the ECCKD_HOST memory space "
+                         "(host arrays in, host arrays out; 0 = skip).  Reported beside the headline, never as it.")
     ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the CPU baseline")
     ap.add_argument("--lut", choices=["fsck", "rrtmgp"], default="fsck",
                     help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
@@ -256,6 +259,37 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, press_min)
         else:
             out["cpu_baseline"] = None
+        out["host_memspace"] = None
+        if args.host_sample > 0 and world == 1 and args.dtype == "f64":
+            # The reference's calling convention: host arrays in and out (ECCKD_HOST).  Every call stages its
+            # arguments over PCIe, so this is the PCIe-inclusive rate of the same two calls.
+            n = min(args.host_sample, ncol)
+            hc = synthetic.columns(0, n, press_min)
+            hgc = pkg.GasConcs(synthetic.GAS_ORDER)
+            for name in synthetic.GAS_ORDER:
+                v = hc[name]
+                if np.isscalar(v):
+                    hgc.set_vmr(name, float(v))
+                elif v.ndim == 1:
+                    hgc.set_vmr_column(name, v)
+                else:
+                    hgc.set_vmr(name, v)
+            hop = pkg.OpticalProps1scl(); hop.alloc_1scl(n, nlay, k)
+            hsrc = pkg.SourceFuncLW(); hsrc.alloc(n, nlay, k)
+            hfl = pkg.FluxesBroadband(np.empty((nlay + 1, n)), np.empty((nlay + 1, n)))
+            hemis = np.ascontiguousarray(np.repeat(hc["sfc_emis"][:, None], k.get_nband(), 1))
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                e = k.gas_optics(None, hc["plev"], hc["tlay"], hc["tsfc"], hgc, hop, hsrc, tlev=hc["tlev"])
+                e = e or pkg.rte_lw(hop, True, hsrc, hemis, hfl, n_gauss_angles=1)
+                dt = time.perf_counter() - t0
+                if e:
+                    raise SystemExit(e)
+                best = dt if best is None else min(best, dt)
+            out["host_memspace"] = {"value": n * nlay * ng / best / 1e6, "unit": "Mcol*lay*gpt/s", "ncol": n,
+                                    "note": "ECCKD_HOST: pageable host arrays staged over PCIe by every call (64 B/cell "
+                                            "of intermediates out and back in); best of 3"}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
