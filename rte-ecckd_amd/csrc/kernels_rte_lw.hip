@@ -20,9 +20,14 @@
 // for the 2*NL doubles per pair that the up sweep needs; the HBM latency is hidden by the
 // explicit prefetch ring instead of by occupancy.
 //
-// NL > 0 requires nlay == NL exactly (no per-layer predicates in the unrolled code).
-// NL == 0 is the any-nlay fallback: trans/source_up go through a global scratch ring instead
-// of registers (twice the memory traffic, but high occupancy).
+// NL > 0, EXACT: nlay == NL exactly, no per-layer predicates in the unrolled code (the 60-layer
+//   benchmark and RFMIP shape).
+// NL > 0, !EXACT: any nlay <= NL.  Layers s >= nlay of the unrolled code are made transparent
+//   (tau = 0: trans = 1, sources 0) and accumulate into a dummy LDS row; the predicate s < nlay is
+//   re-derived from an opaque copy of nlay at every use -- as a plain comparison the optimiser
+//   hoists NL loop-invariant booleans and spills the SGPR file.  Costs NL/nlay of the arithmetic.
+// NL == 0 is the any-nlay fallback (nlay > 96): trans/source_up go through a global scratch ring
+// instead of registers (twice the memory traffic, but high occupancy).
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -66,7 +71,7 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #endif
 }
 
-template <typename real, int NL, int CW>
+template <typename real, int NL, int CW, bool EXACT>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   constexpr int GW = 64 / CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
@@ -79,7 +84,15 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   const bool owner = gs == 0;
   const int ncol = a.ncol, nlay = a.nlay, ng = a.ng;
   const int nlev = nlay + 1;
-  double *acc_dn = acc, *acc_up = acc + nlev * CW;
+  // (padded variants: one extra row per array, index nlev, swallows the absent layers' adds)
+  constexpr bool PAD = NL > 0 && !EXACT;
+  double *acc_dn = acc, *acc_up = acc + (nlev + (PAD ? 1 : 0)) * CW;
+  // s < nlay with nlay read through an opaque asm (see the header comment)
+  auto present = [&](int s_) {
+    int nl = nlay;
+    asm volatile("" : "+s"(nl));
+    return s_ < nl;
+  };
   const real pi = (real)acos(-1.);
   const real tau_thresh = sizeof(real) == 8 ? (real)1.4901161193847656e-08 : (real)3.4526698300124393e-04;   // sqrt(epsilon(1._wp))
   // layer / level walked s-th from the top lives at index l0 + s*lstep
@@ -95,7 +108,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     const long col = tile * CW + cl;
     const bool valid = col < ncol;
     const long cc = valid ? col : (long)ncol - 1;
-    for (int i = lane; i < 2 * nlev * CW; i += 64) acc[i] = 0.;
+    for (int i = lane; i < 2 * (nlev + (PAD ? 1 : 0)) * CW; i += 64) acc[i] = 0.;
 
     [[maybe_unused]] real T[NL > 0 ? NL : 1], SU[NL > 0 ? NL : 1];
     [[maybe_unused]] real *sT = nullptr, *sSU = nullptr;
@@ -116,7 +129,9 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       qn = cc + (long)ncol * nlay * gg + (long)ncol * lay0;
       asm volatile("" : "+v"(qn));
     };
-    auto issue = [&](int slot) {
+    // `sl` = layer being requested (compile-time in the unrolled code); in the padded variants the
+    // offset stops advancing at the last real layer, so absent layers re-read it (finite data).
+    auto issue = [&](int slot, int sl) {
 #ifndef ECCKD_LW_PLAIN_LOADS   // nontemporal: read-once streams
       ptau[slot] = __builtin_nontemporal_load(P(a.tau) + qn);
       play[slot] = __builtin_nontemporal_load(P(a.lay_source) + qn);
@@ -128,21 +143,21 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       pbdn[slot] = Bdn[qn];
       pbup[slot] = Bup[qn];
 #endif
-      qn += qstep;
+      if (!PAD || present(sl + 1)) qn += qstep;
       asm volatile("" : "+v"(qn));
     };
     // Same, but pinned into the recurrence: the empty asm also "modifies" the running
     // intensity, so the loads for layer s+kPF cannot be hoisted above layer s-1 (without this
     // the scheduler issues dozens of layers of loads up front and spills the register file).
-    auto issue_after = [&](int slot, real &pin) {
+    auto issue_after = [&](int slot, int sl, real &pin) {
       asm volatile("" : "+v"(qn), "+v"(pin));
-      issue(slot);
+      issue(slot, sl);
     };
 
     if constexpr (NL > 0) {
       pair_start(0);
 #pragma unroll
-      for (int s = 0; s < kPF; ++s) issue(s);
+      for (int s = 0; s < kPF; ++s) issue(s, s);
     }
 
     for (int it = 0; it < niter; ++it) {
@@ -160,6 +175,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       real I = real(0);   // no incident diffuse flux: radn_dn(top) = 0
       auto layer = [&](int s, real tau, real lay, real bdn, real bup, real &t_out,
                        real &su_out) {
+        const bool act = !PAD || present(s);
+        if (PAD) tau = act ? tau : real(0);   // absent layer: trans = 1, both sources 0
         const real tl = tau * D;
         const real t = exp(-tl);
         const real omt = real(1) - t;
@@ -175,7 +192,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         su_out = su;
         t_out = t;
         const real v = gsum<real, CW>(wfac * I);
-        acc_add(&acc_dn[s * CW + cl], v, owner);
+        acc_add(&acc_dn[(act ? s : nlev) * CW + cl], v, owner);
         I = t * I + sdn;
       };
       if constexpr (NL > 0) {
@@ -183,7 +200,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         for (int s = 0; s < NL; ++s) {
           const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF],
                        bup = pbup[s % kPF];
-          if (s + kPF < NL) issue_after(s % kPF, I);
+          if (s + kPF < NL) issue_after(s % kPF, s + kPF, I);
           layer(s, tau, lay, bdn, bup, T[s], SU[s]);
           if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -191,7 +208,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         if (it + 1 < niter) {
           pair_start(it + 1);
 #pragma unroll
-          for (int s = 0; s < kPF; ++s) issue(s);
+          for (int s = 0; s < kPF; ++s) issue(s, s);
         }
       } else {
         for (int s = 0; s < nlay; ++s) {
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       real U = I * (real(1) - eps) + eps * sfc_src;
       auto up = [&](int s, real t, real su) {
         const real v = gsum<real, CW>(wfac * U);
-        acc_add(&acc_up[(s + 1) * CW + cl], v, owner);
+        acc_add(&acc_up[((!PAD || present(s)) ? s + 1 : nlev) * CW + cl], v, owner);
         U = t * U + su;
       };
       if constexpr (NL > 0) {
@@ -238,10 +255,10 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
 
 constexpr int kGenericWaves = 4096;
 
-template <typename real, int NL, int CW>
+template <typename real, int NL, int CW, bool EXACT>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<real, NL, CW>;
-  const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1) * CW;
+  auto k = rte_lw_kernel<real, NL, CW, EXACT>;
+  const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + ((NL > 0 && !EXACT) ? 1 : 0)) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -252,11 +269,23 @@ hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
+
+template <typename real>
+hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
+  constexpr int CW = sizeof(real) == 8 ? ECCKD_LW_CW : ECCKD_LW_CW_F32;
+  if (a.nlay == 60) return launch_one<real, 60, CW, true>(a, s);
+  if (a.nlay <= 32) return launch_one<real, 32, CW, false>(a, s);
+  if (a.nlay <= 64) return launch_one<real, 64, CW, false>(a, s);
+  if (a.nlay <= kMaxRegisterLayers) return launch_one<real, 96, CW, false>(a, s);
+  return launch_one<real, 0, 16, true>(a, s);
+}
+
 }  // namespace
 
 size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
   (void)ng;
-  if (nlay == 60) return 0;
+  if (nlay <= kMaxRegisterLayers) return 0;
   long tiles = ((long)ncol + 15) / 16;
   if (tiles > kGenericWaves) tiles = kGenericWaves;
   return sizeof(double) * 2 * (size_t)nlay * 64 * (size_t)tiles;
@@ -264,10 +293,8 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
 
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
-  static_assert(kPF <= 60, "prefetch ring deeper than the layer count");
-  if (a.f32) return a.nlay == 60 ? launch_one<float, 60, ECCKD_LW_CW_F32>(a, s) : launch_one<float, 0, 16>(a, s);
-  if (a.nlay == 60) return launch_one<double, 60, ECCKD_LW_CW>(a, s);
-  return launch_one<double, 0, 16>(a, s);
+  static_assert(kPF <= 32, "prefetch ring deeper than the smallest unrolled layer count");
+  return a.f32 ? launch_real<float>(a, s) : launch_real<double>(a, s);
 }
 
 }  // namespace ecckd

@@ -206,11 +206,14 @@ def test_rte_lw_vs_oracle(pkg, gpu, oracle_mod, lw, nmus):
     assert pkg.rte_lw(op, True, src, t(cols["sfc_emis"][:, None]), fl, n_gauss_angles=5) != ""
 
 
-@pytest.mark.parametrize("nlay,top_at_1", [(60, False), (5, True), (61, True), (91, False)])
+@pytest.mark.parametrize("nlay,top_at_1", [(60, False), (5, True), (32, False), (33, True), (61, True), (64, False),
+                                           (91, False), (96, True), (97, True), (137, False)])
 def test_rte_lw_other_layer_counts_and_orientation(pkg, gpu, oracle_mod, nlay, top_at_1):
-    """nlay != 60 takes the any-nlay solver path; top_at_1 = .false. walks the arrays backwards."""
+    """nlay != 60 takes the padded register-resident variants (<= 32, <= 64, <= 96 layers) or, beyond 96
+    layers, the scratch-ring path; top_at_1 = .false. walks the arrays backwards; 1-3 quadrature angles."""
     import torch
     rng = np.random.default_rng(nlay)
+    nmus = 1 + nlay % 3
     ng, ncol = 7, 77
     tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
     lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
@@ -223,16 +226,16 @@ def test_rte_lw_other_layer_counts_and_orientation(pkg, gpu, oracle_mod, nlay, t
     src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
     fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu),
                              torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu))
-    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl) == ""
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus) == ""
     emis_gpt = np.stack([emis[:, 0]] * 3 + [emis[:, 1]] * 4)
-    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, emis_gpt, sfc, top_at_1=top_at_1)
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, emis_gpt, sfc, top_at_1=top_at_1, nmus=nmus)
     assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
     assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
     # host memspace gives the same numbers
     fl2 = pkg.FluxesBroadband(np.empty((nlay + 1, ncol)), np.empty((nlay + 1, ncol)))
     op2 = pkg.OpticalProps1scl(); op2.tau = tau; op2.band2gpt = b2g
     s2 = pkg.SourceFuncLW(); s2.lay_source, s2.lev_source_inc, s2.lev_source_dec, s2.sfc_source = lay, inc, dec, sfc
-    assert pkg.rte_lw(op2, top_at_1, s2, np.ascontiguousarray(emis), fl2) == ""
+    assert pkg.rte_lw(op2, top_at_1, s2, np.ascontiguousarray(emis), fl2, n_gauss_angles=nmus) == ""
     assert np.array_equal(fl2.flux_up, fl.flux_up.cpu().numpy())
 
 
