@@ -26,8 +26,9 @@
 //   (tau = 0: trans = 1, sources 0) and accumulate into a dummy LDS row; the predicate s < nlay is
 //   re-derived from an opaque copy of nlay at every use -- as a plain comparison the optimiser
 //   hoists NL loop-invariant booleans and spills the SGPR file.  Costs NL/nlay of the arithmetic.
-// NL == 0 is the any-nlay fallback (nlay > 96): trans/source_up go through a global scratch ring
-// instead of registers (twice the memory traffic, but high occupancy).
+// NL > 0, OVER: nlay > NL.  The bottom NL layers run from registers as above; trans/source_up of
+//   the top nlay - NL layers go through a per-wave global scratch ring (16 B/cell written and read
+//   back for those layers only).
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -71,8 +72,9 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #endif
 }
 
-template <typename real, int NL, int CW, bool EXACT>
+template <typename real, int NL, int CW, bool EXACT, bool OVER>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
+  static_assert(NL > 0 && !(EXACT && OVER), "unrolled layer count; overflow only in the padded form");
   constexpr int GW = 64 / CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
   double *acc = reinterpret_cast<double *>(acc_raw);   // [2][nlay+1][CW], double in both precisions
@@ -85,9 +87,17 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   const int ncol = a.ncol, nlay = a.nlay, ng = a.ng;
   const int nlev = nlay + 1;
   // (padded variants: one extra row per array, index nlev, swallows the absent layers' adds)
-  constexpr bool PAD = NL > 0 && !EXACT;
+  constexpr bool PAD = !EXACT;
+  const int nover = OVER ? (nlay > NL ? nlay - NL : 0) : 0;   // layers above the register-resident ones
   double *acc_dn = acc, *acc_up = acc + (nlev + (PAD ? 1 : 0)) * CW;
   // s < nlay with nlay read through an opaque asm (see the header comment)
+  // index of the s_-th register-resident layer among all layers (opaque for the same reason)
+  auto abs_layer = [&](int s_) {
+    if (!OVER) return s_;
+    int no = nover;
+    asm volatile("" : "+s"(no));
+    return no + s_;
+  };
   auto present = [&](int s_) {
     int nl = nlay;
     asm volatile("" : "+s"(nl));
@@ -110,11 +120,11 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     const long cc = valid ? col : (long)ncol - 1;
     for (int i = lane; i < 2 * (nlev + (PAD ? 1 : 0)) * CW; i += 64) acc[i] = 0.;
 
-    [[maybe_unused]] real T[NL > 0 ? NL : 1], SU[NL > 0 ? NL : 1];
+    real T[NL], SU[NL];
     [[maybe_unused]] real *sT = nullptr, *sSU = nullptr;
-    if constexpr (NL == 0) {
-      sT = Q(a.scratch) + ((long)blockIdx.x * 2 * nlay) * 64 + lane;
-      sSU = sT + (long)nlay * 64;
+    if constexpr (OVER) {
+      sT = Q(a.scratch) + ((long)blockIdx.x * 2 * nover) * 64 + lane;
+      sSU = sT + (long)nover * 64;
     }
     real ptau[kPF], play[kPF], pbdn[kPF], pbup[kPF];
 
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     auto pair_start = [&](int it) {
       const int g = (it / a.nmus) * GW + gs;
       const int gg = g < ng ? g : ng - 1;
-      qn = cc + (long)ncol * nlay * gg + (long)ncol * lay0;
+      qn = cc + (long)ncol * nlay * gg + (long)ncol * (lay0 + lstep * nover);
       asm volatile("" : "+v"(qn));
     };
     // `sl` = layer being requested (compile-time in the unrolled code); in the padded variants the
@@ -143,7 +153,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       pbdn[slot] = Bdn[qn];
       pbup[slot] = Bup[qn];
 #endif
-      if (!PAD || present(sl + 1)) qn += qstep;
+      if (!PAD || present(abs_layer(sl + 1))) qn += qstep;
       asm volatile("" : "+v"(qn));
     };
     // Same, but pinned into the recurrence: the empty asm also "modifies" the running
@@ -154,11 +164,9 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       issue(slot, sl);
     };
 
-    if constexpr (NL > 0) {
-      pair_start(0);
+    pair_start(0);
 #pragma unroll
-      for (int s = 0; s < kPF; ++s) issue(s, s);
-    }
+    for (int s = 0; s < kPF; ++s) issue(s, s);
 
     for (int it = 0; it < niter; ++it) {
       const int gi = it / a.nmus, k = it - gi * a.nmus;
@@ -195,29 +203,27 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         acc_add(&acc_dn[(act ? s : nlev) * CW + cl], v, owner);
         I = t * I + sdn;
       };
-      if constexpr (NL > 0) {
-#pragma unroll
-        for (int s = 0; s < NL; ++s) {
-          const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF],
-                       bup = pbup[s % kPF];
-          if (s + kPF < NL) issue_after(s % kPF, s + kPF, I);
-          layer(s, tau, lay, bdn, bup, T[s], SU[s]);
-          if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // the next pair's first layers start streaming while the up sweep runs from registers
-        if (it + 1 < niter) {
-          pair_start(it + 1);
-#pragma unroll
-          for (int s = 0; s < kPF; ++s) issue(s, s);
-        }
-      } else {
-        for (int s = 0; s < nlay; ++s) {
+      if constexpr (OVER) {   // the layers above the register-resident ones: plain loads, scratch ring
+        for (int s = 0; s < nover; ++s) {
           const long q = base + (long)ncol * (lay0 + lstep * s);
           real t, su;
           layer(s, P(a.tau)[q], P(a.lay_source)[q], Bdn[q], Bup[q], t, su);
           sT[(long)s * 64] = t;
           sSU[(long)s * 64] = su;
         }
+      }
+#pragma unroll
+      for (int s = 0; s < NL; ++s) {
+        const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF], bup = pbup[s % kPF];
+        if (s + kPF < NL) issue_after(s % kPF, s + kPF, I);
+        layer(abs_layer(s), tau, lay, bdn, bup, T[s], SU[s]);
+        if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next pair's first register-resident layers start streaming while the up sweep runs
+      if (it + 1 < niter) {
+        pair_start(it + 1);
+#pragma unroll
+        for (int s = 0; s < kPF; ++s) issue(s, s);
       }
       {
         const real v = gsum<real, CW>(wfac * I);
@@ -230,11 +236,10 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         acc_add(&acc_up[((!PAD || present(s)) ? s + 1 : nlev) * CW + cl], v, owner);
         U = t * U + su;
       };
-      if constexpr (NL > 0) {
 #pragma unroll
-        for (int s = NL - 1; s >= 0; --s) up(s, T[s], SU[s]);
-      } else {
-        for (int s = nlay - 1; s >= 0; --s) up(s, sT[(long)s * 64], sSU[(long)s * 64]);
+      for (int s = NL - 1; s >= 0; --s) up(abs_layer(s), T[s], SU[s]);
+      if constexpr (OVER) {
+        for (int s = nover - 1; s >= 0; --s) up(s, sT[(long)s * 64], sSU[(long)s * 64]);
       }
       {
         const real v = gsum<real, CW>(wfac * U);
@@ -253,32 +258,34 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   }
 }
 
-constexpr int kGenericWaves = 4096;
+constexpr int kOverWaves = 2048;   // grid of the overflow variant (its scratch ring is per wave)
+constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
+constexpr int kOverCW = 16;   // 16 * (nlay + 2) * CW bytes of LDS accumulators per wave: 16 columns keep 4 waves per CU
 
-template <typename real, int NL, int CW, bool EXACT>
+template <typename real, int NL, int CW, bool EXACT, bool OVER>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<real, NL, CW, EXACT>;
-  const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + ((NL > 0 && !EXACT) ? 1 : 0)) * CW;
+  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER>;
+  const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + (EXACT ? 0 : 1)) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   long tiles = ((long)a.ncol + CW - 1) / CW;
-  if (NL == 0 && tiles > kGenericWaves) tiles = kGenericWaves;
+  if (OVER && tiles > kOverWaves) tiles = kOverWaves;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 
-constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
-
 template <typename real>
 hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
   constexpr int CW = sizeof(real) == 8 ? ECCKD_LW_CW : ECCKD_LW_CW_F32;
-  if (a.nlay == 60) return launch_one<real, 60, CW, true>(a, s);
-  if (a.nlay <= 32) return launch_one<real, 32, CW, false>(a, s);
-  if (a.nlay <= 64) return launch_one<real, 64, CW, false>(a, s);
-  if (a.nlay <= kMaxRegisterLayers) return launch_one<real, 96, CW, false>(a, s);
-  return launch_one<real, 0, 16, true>(a, s);
+  if (a.nlay == 60) return launch_one<real, 60, CW, true, false>(a, s);
+  if (a.nlay <= 32) return launch_one<real, 32, CW, false, false>(a, s);
+  if (a.nlay <= 48) return launch_one<real, 48, CW, false, false>(a, s);
+  if (a.nlay <= 64) return launch_one<real, 64, CW, false, false>(a, s);
+  if (a.nlay <= 80) return launch_one<real, 80, CW, false, false>(a, s);
+  if (a.nlay <= kMaxRegisterLayers) return launch_one<real, 96, CW, false, false>(a, s);
+  return launch_one<real, 96, kOverCW, false, true>(a, s);
 }
 
 }  // namespace
@@ -286,9 +293,9 @@ hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
 size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
   (void)ng;
   if (nlay <= kMaxRegisterLayers) return 0;
-  long tiles = ((long)ncol + 15) / 16;
-  if (tiles > kGenericWaves) tiles = kGenericWaves;
-  return sizeof(double) * 2 * (size_t)nlay * 64 * (size_t)tiles;
+  long tiles = ((long)ncol + kOverCW - 1) / kOverCW;
+  if (tiles > kOverWaves) tiles = kOverWaves;
+  return sizeof(double) * 2 * (size_t)(nlay - kMaxRegisterLayers) * 64 * (size_t)tiles;
 }
 
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {

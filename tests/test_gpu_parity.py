@@ -207,10 +207,10 @@ def test_rte_lw_vs_oracle(pkg, gpu, oracle_mod, lw, nmus):
 
 
 @pytest.mark.parametrize("nlay,top_at_1", [(60, False), (5, True), (32, False), (33, True), (61, True), (64, False),
-                                           (91, False), (96, True), (97, True), (137, False)])
+                                           (80, True), (91, False), (96, True), (97, True), (137, False), (200, True)])
 def test_rte_lw_other_layer_counts_and_orientation(pkg, gpu, oracle_mod, nlay, top_at_1):
-    """nlay != 60 takes the padded register-resident variants (<= 32, <= 64, <= 96 layers) or, beyond 96
-    layers, the scratch-ring path; top_at_1 = .false. walks the arrays backwards; 1-3 quadrature angles."""
+    """nlay != 60 takes the padded register-resident variants (<= 32, 48, 64, 80, 96 layers) or, beyond 96
+    layers, the overflow variant (bottom 96 layers in registers, the rest through a scratch ring); top_at_1 = .false. walks the arrays backwards; 1-3 quadrature angles."""
     import torch
     rng = np.random.default_rng(nlay)
     nmus = 1 + nlay % 3
