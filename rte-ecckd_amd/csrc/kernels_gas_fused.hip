@@ -323,8 +323,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       ipmin = pressure_point<real>(real(0), smin, lp0, ud_dlp, np).ip0;
       ipmax = pressure_point<real>(real(0), smax, lp0, ud_dlp, np).ip0;
     }
-    if (R >= 2 && ipmin <= ipmax && !(slab_lo >= 0 && ipmin - 1 >= slab_lo && ipmax <= slab_lo + R - 1)) {
-      slab_lo = min(ipmin - 1, np - R);
+    auto stage_slab = [&](int lo) {   // pressure rows [lo, lo + R) of every active table -> LDS
+      slab_lo = lo;
       const int rows_b = R * nt;
       const int items_b = rows_b * t.nbil;
       for (int q = wave; q < items_b; q += kWaves) {
@@ -343,6 +343,24 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
           real *dst = lds + L.lut + q * L.SL;
           for (int g = lane; g < ng; g += 64) dst[g] = src[g];
         }
+      }
+    };
+    // A slab serves R - 1 consecutive values of the pressure index.  When the columns of the
+    // segment span more (orography), the segment is walked once per slab POSITION: a wave handles
+    // a tile in the pass whose position holds all of its lanes; a wave whose lanes straddle two
+    // positions handles it once, in the pass of its lowest lane, through the slow path.
+    const int span = R >= 2 ? R - 1 : 1;
+    const int npos = (R >= 2 && ipmin <= ipmax) ? (ipmax - ipmin + span) / span : 1;
+    for (int pos = 0; pos < npos; ++pos) {
+    const int pos_lo = npos > 1 ? ipmin + pos * span : -0x40000000;   // pressure indices of this pass
+    const int pos_hi = npos > 1 ? pos_lo + span - 1 : 0x40000000;
+    if (pos > 0) __syncthreads();   // the previous pass's LDS reads are done
+    if (R >= 2 && ipmin <= ipmax) {
+      if (npos > 1) {
+        const int lo = min(pos_lo - 1, np - R);
+        if (lo != slab_lo) stage_slab(lo);
+      } else if (!(slab_lo >= 0 && ipmin - 1 >= slab_lo && ipmax <= slab_lo + R - 1)) {
+        stage_slab(min(ipmin - 1, np - R));
       }
     }
     __syncthreads();
@@ -394,6 +412,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       const PPoint<real> pp = pressure_point<real>(p0, p1, lp0, ud_dlp, np);
       const int ip0 = pp.ip0;
+      bool straddles = false;
+      if (npos > 1) {   // block-uniform
+        // handled in an earlier pass (there as a straddling wave, if mixed), or due in a later one
+        if (__any(ip0 < pos_lo) || __all(ip0 > pos_hi)) {
+#ifndef ECCKD_FUSED_NO_PREFETCH
+          load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
+#endif
+          continue;
+        }
+        straddles = __any(ip0 > pos_hi);
+      }
       const int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
 
@@ -446,7 +475,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       }
       const real moles = dp * gw;   // :313-314 (SW)
       // ragged waves (end of the column range) and waves outside the staged rows go the slow way
-      const bool fast = __all(inslab && pair_ok && inwin);
+      const bool fast = __all(inslab && pair_ok && inwin) && !straddles;
       const int ip0_ = ip0, it0_ = it0, iv0_ = iv0;
 #ifndef ECCKD_FUSED_NO_PREFETCH
       load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
@@ -690,6 +719,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
           Q(a.sfc_source)[c + (long)ncol * g] = div_pi(qs.w0 * p0r[g] + qs.w1 * p1r[g], pi, rpi);
       }
     }
+    }   // slab positions
   }
 }
 

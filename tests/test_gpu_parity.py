@@ -76,6 +76,32 @@ def test_lw_gas_optics_edge_branches(pkg, gpu, oracle_mod, lw):
     check_lw(pkg, k, m, oracle_mod, edge_columns(k.get_press_min()), gpu)
 
 
+def orography_ramp(press_min, ncol=2048, c0=40):
+    """Surface pressure ramps smoothly from 50 to 103 kPa across the columns: at the lower layers a
+    4096-column segment spans more pressure rows than the LDS slab holds, so the fused kernel walks it once
+    per slab position; most waves sit in one position, a few straddle two."""
+    c = synthetic.columns(c0, ncol, press_min)
+    c = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    ps = np.linspace(50000.0, 103000.0, ncol)
+    eta = (np.arange(61, dtype=np.float64) / 60) ** 2
+    ptop = c["plev"][0, 0]
+    c["plev"] = np.ascontiguousarray(ptop + (ps[None, :] - ptop) * eta[:, None])
+    return c
+
+
+@pytest.mark.parametrize("ncol", [2048, 3000])
+def test_lw_gas_optics_orography(pkg, gpu, oracle_mod, lw, ncol):
+    k, m = lw
+    check_lw(pkg, k, m, oracle_mod, orography_ramp(k.get_press_min(), ncol), gpu)
+    rev = orography_ramp(k.get_press_min(), ncol)          # descending ramp, shuffled blocks of 64 columns
+    perm = np.random.default_rng(ncol).permutation(ncol // 64 + 1)
+    idx = np.concatenate([np.arange(b * 64, min((b + 1) * 64, ncol)) for b in perm])
+    for key, v in rev.items():
+        if isinstance(v, np.ndarray):
+            rev[key] = np.ascontiguousarray(v[..., idx])
+    check_lw(pkg, k, m, oracle_mod, rev, gpu)
+
+
 def test_lw_gas_lists(pkg, gpu, oracle_mod, lw):
     """gas_desc order, unknown gases, composite-once, missing composite (src/gas_optics_ecckd.f90:348-374)."""
     k, m = lw
@@ -182,6 +208,9 @@ def test_two_lut_gases_and_negative_tables(pkg, gpu, oracle_mod, lw):
     names = ["co2", "h2o", "weird", "h2o_b", "o3", "ch4"]
     over = {"weird": 1e-4, "h2o_b": cols["h2o"] * 0.5}
     check_lw(pkg, k2, m2, oracle_mod, cols, gpu, names=names, overrides=over)
+    # the second pass accumulates into tau: a segment walked once per slab position must not add twice
+    wide = orography_ramp(k.get_press_min(), 1500, c0=21)
+    check_lw(pkg, k2, m2, oracle_mod, wide, gpu, names=names, overrides={"weird": 1e-4, "h2o_b": wide["h2o"] * 0.5})
 
 
 @pytest.mark.parametrize("nmus", [1, 2, 3, 4])
