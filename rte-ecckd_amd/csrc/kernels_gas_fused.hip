@@ -5,10 +5,10 @@
 // calculate_optical_depth x ngas + the tau accumulation (:64-241, :348-374),
 // calculate_planck_function x 3 (:245-289, :407-424) or the Rayleigh epilogue (:293-319, :455-460).
 //
-// Why one kernel: on gfx950 the interpolation is bound by LDS read issue (36 coefficient reads
-// per cell) and fp64 VALU, the Planck sources by HBM stores (24 B/cell).  Run back to back they
-// take the sum; fused, the arithmetic hides under the stores and the pass is HBM-bound
-// (32 B/cell written: tau, lay_source, lev_source_inc, lev_source_dec).
+// Why one kernel: the interpolation is bound by fp64 VALU issue (61 fp64 operations and 21 16-byte
+// LDS reads per cell pair), the Planck sources by HBM stores (24 B/cell).  Run back to back they
+// take the sum; fused, most of the arithmetic hides under the stores (32 B/cell written: tau,
+// lay_source, lev_source_inc, lev_source_dec).
 //
 // Arithmetic ("fast" mode, the default): the four (eight) interpolation weights of a cell are
 // multiplied out once per (column,layer) and every coefficient costs one FMA,
@@ -22,8 +22,10 @@
 // reference's order and are bit-identical.
 //
 // Mapping: lane -> column, block = kBlock columns of ONE layer (grid.y), LDS = slab of R pressure
-// rows of every active table (+ the whole Planck table), rows padded to an odd length; see
-// kernels_tau.hip for the slab logic, which is the same.
+// rows of every active table + the Planck table (or a window of it), row strides == 2 (mod 4)
+// doubles.  Per segment of kSeg tiles a pre-pass finds the pressure-row (and Planck-row) range and
+// places the slab; segments spanning more rows than the slab holds are walked once per slab
+// position; waves with a lane outside the staged rows read the tables from global memory.
 #include <cstdlib>
 #include <type_traits>
 
@@ -35,13 +37,9 @@ namespace {
 #ifndef ECCKD_FUSED_BLOCK
 #define ECCKD_FUSED_BLOCK 512
 #endif
-#ifndef ECCKD_FUSED_SPAN
-#define ECCKD_FUSED_SPAN 4
-#endif
 constexpr int kBlock = ECCKD_FUSED_BLOCK;
 constexpr int kWaves = kBlock / 64;
 constexpr int kSeg = 8;    // tiles between two slab-range checks (block barriers)
-constexpr int kSpan = ECCKD_FUSED_SPAN;
 
 // Compile-time loop: f(integral_constant<int, I>) for I = I0 .. N-1, as straight-line code.  The
 // item pipeline below must be fully unrolled (its buffer indices and item kinds are static);
@@ -161,39 +159,46 @@ __device__ __forceinline__ float swap_adjacent(float x) {
 // 16-byte store per lane instead of two 8-byte ones: the lanes of an (even, odd) column pair
 // exchange one value, then the even lane writes both columns of plane g and the odd lane both
 // columns of plane g+1.  Per CU the store path moves ~7 B/clk with dwordx2 and about twice that with
-// dwordx4 (the kernel was store-issue bound).  Called by all lanes of the wave, and every lane
-// stores: the item pipeline only runs for waves whose 64 columns all exist (ragged waves take the
-// per-g-point path), so the store is unconditional -- no exec mask, no skip branch, and the
-// compiler's vmcnt bookkeeping stays exact across a tile (a load may wait for "all but the last 16
-// stores" instead of "every store").
+// dwordx4 (the kernel was store-issue bound).  Called by all lanes of the wave.
+//   masked (wave-uniform) == false: every lane stores, no exec mask.
+//   masked == true: the wave holds lanes that are not handled in this pass (columns beyond ncol,
+//   or columns that belong to another slab position): the lanes with `active` store their own
+//   column of both planes with two 8-byte stores, the others store nothing.
 //   base: wave-uniform RUNNING pointer to (column 0, plane g) of the array, advanced by two planes
 //   (plane2 elements) after the store -- the g-pairs of an array are stored in ascending order, so
 //   one pointer per array walks the whole tile and nothing per (array, g-pair) is loop invariant;
 //   voff: per-lane BYTE offset sizeof(real) * ((c - odd) + (odd ? plane : 0)), 32 bits, shared by
-//   the four output arrays.
+//   the four output arrays; coff: sizeof(real) * c.
 template <typename real>
-__device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned voff, real v0, real v1, bool odd) {
+__device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned voff, unsigned coff, real v0, real v1,
+                                           bool odd, bool masked, bool active) {
   typedef real double2_t __attribute__((ext_vector_type(2)));
-  const real recv = swap_adjacent(odd ? v0 : v1);
-  double2_t out;
-  out[0] = odd ? recv : v0;
-  out[1] = odd ? v1 : recv;
   // Pin the pointer in SGPRs right here: left alone, the optimiser precomputes one pointer per
   // (array, g-pair) outside the loops (32 SGPRs, spilled to VGPR lanes and read back per store) or
   // hoists the per-lane sum array + voff (32 VGPRs).
   asm volatile("" : "+s"(base));
-#ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
   typedef __attribute__((address_space(1))) char gchar;          // global, not flat: the pin
   typedef __attribute__((address_space(1))) double2_t gdouble2;  // hides the pointer's origin
+  typedef __attribute__((address_space(1))) real greal;
   gchar *gbase = (gchar *)base;
-#ifndef ECCKD_PLAIN_STORES   // nontemporal: the outputs are written once and read by the next kernel
-  __builtin_nontemporal_store(out, reinterpret_cast<gdouble2 *>(gbase + voff));
+  if (!masked) {
+    const real recv = swap_adjacent(odd ? v0 : v1);
+    double2_t out;
+    out[0] = odd ? recv : v0;
+    out[1] = odd ? v1 : recv;
+#ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
+#ifndef ECCKD_PLAIN_STORES    // nontemporal: the outputs are written once and read by the next kernel
+    __builtin_nontemporal_store(out, reinterpret_cast<gdouble2 *>(gbase + voff));
 #else
-  *reinterpret_cast<gdouble2 *>(gbase + voff) = out;
+    *reinterpret_cast<gdouble2 *>(gbase + voff) = out;
 #endif
 #else
-  asm volatile("" :: "v"(out));
+    asm volatile("" :: "v"(out));
 #endif
+  } else if (active) {
+    *reinterpret_cast<greal *>(gbase + coff) = v0;
+    *reinterpret_cast<greal *>(gbase + (plane2 / 2) * (long)sizeof(real) + coff) = v1;
+  }
   base += plane2;
 }
 
@@ -397,7 +402,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const long c = tile * kBlock + tid;
       const bool valid = c < ncol;
       const bool odd = (tid & 1) != 0;
-      const bool pair_ok = (c | 1) < ncol;   // both columns of this lane pair exist
       const long cc = c < ncol ? c : (long)ncol - 1;
       // ---- setup: the inputs of this tile were loaded one tile ahead (see above) ----
 #ifdef ECCKD_FUSED_NO_PREFETCH
@@ -412,19 +416,20 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
       const PPoint<real> pp = pressure_point<real>(p0, p1, lp0, ud_dlp, np);
       const int ip0 = pp.ip0;
-      bool straddles = false;
-      if (npos > 1) {   // block-uniform
-        // handled in an earlier pass (there as a straddling wave, if mixed), or due in a later one
-        if (__any(ip0 < pos_lo) || __all(ip0 > pos_hi)) {
+      // Lanes this pass is responsible for: existing columns whose pressure index belongs to the slab
+      // position of the pass (with a single position: every existing column).
+      const bool own = valid && ip0 >= pos_lo && ip0 <= pos_hi;
+      if (!__any(own)) {   // nothing of this wave in this pass
 #ifndef ECCKD_FUSED_NO_PREFETCH
-          load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
+        load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
 #endif
-          continue;
-        }
-        straddles = __any(ip0 > pos_hi);
+        continue;
       }
-      const int ipl = ip0 - 1 - slab_lo;
+      const bool lowest = !__any(valid && ip0 < pos_lo);   // this is the pass of the wave's lowest lane
+      // (lanes of other passes are carried along with a clamped row: finite values, never stored)
+      int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
+      ipl = ipl < 0 ? 0 : (ipl > R - 2 ? (R >= 2 ? R - 2 : 0) : ipl);
 
       const real t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
       real temperature_index = udiv(Tlayer - t0, ud_dt);
@@ -474,8 +479,15 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         ql1.off = (ql1.row - pw_lo) * L.SP;
       }
       const real moles = dp * gw;   // :313-314 (SW)
-      // ragged waves (end of the column range) and waves outside the staged rows go the slow way
-      const bool fast = __all(inslab && pair_ok && inwin) && !straddles;
+      // A wave with a lane that no slab position can serve (outside the Planck window, or no slab at
+      // all) goes through the tables-from-global-memory path, all its lanes at once, in the pass of
+      // its lowest lane.  Every other wave runs the item pipeline in each pass it owns lanes of:
+      // all 64 lanes owned -> paired 16-byte stores, else the owned lanes store on their own.
+      const bool slow_wave = __any(valid && !(inwin && R >= 2 && slab_lo >= 0));
+      const bool fast = !slow_wave;
+      const bool active = own && inslab;
+      const bool masked_wave = !__all(active);
+      const bool mine = slow_wave ? (lowest && valid) : active;   // lanes whose results this pass stores
       const int ip0_ = ip0, it0_ = it0, iv0_ = iv0;
 #ifndef ECCKD_FUSED_NO_PREFETCH
       load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
@@ -513,6 +525,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         real *w_lay = MODE == MODE_LW ? Q(a.lay_source) + (long)ncol * j : nullptr;
         real *w_dec = MODE == MODE_LW && a.tlev ? Q(a.lev_source_dec) + (long)ncol * j : nullptr;
         real *w_inc = MODE == MODE_LW && a.tlev ? Q(a.lev_source_inc) + (long)ncol * j : nullptr;
+        // Two copies of the chunk loop: with every lane owned (the common case) the stores are the
+        // unconditional paired ones; the masked copy is for ragged waves and waves split between
+        // slab positions.  A run-time flag instead costs a branch per store and ~2 % of the kernel.
+        auto chunks = [&](auto masked_c) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(masked_c)::value;
         for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
           real acc[GC];
           if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
@@ -600,15 +617,15 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair<real>(w_tau, plane2, voff, t0_, t1_, odd);
+                        store_pair<real>(w_tau, plane2, voff, coff, t0_, t1_, odd, masked, active);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair<real>(w_ssa, plane2, voff, r0 / t0_, r1 / t1_, odd);
-                          store_pair<real>(w_g, plane2, voff, real(0), real(0), odd);
+                          store_pair<real>(w_ssa, plane2, voff, coff, r0 / t0_, r1 / t1_, odd, masked, active);
+                          store_pair<real>(w_g, plane2, voff, coff, real(0), real(0), odd, masked, active);
                         }
                       } else {
-                        store_pair<real>(w_tau, plane2, voff, acc[g], acc[g + 1], odd);
+                        store_pair<real>(w_tau, plane2, voff, coff, acc[g], acc[g + 1], odd, masked, active);
                       }
-                    } else if (gb + g < ng) {   // odd ng: last g-point alone
+                    } else if (gb + g < ng && active) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
                       if (MODE == MODE_SW) {
                         const real ray = moles * P(t.rayleigh)[gb + g];
@@ -633,9 +650,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                     v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
                   }
                   if (both) {
-                    store_pair<real>(w_lay, plane2, voff, vl[0], vl[1], odd);
-                    if (a.tlev) store_pair<real>(w_dec, plane2, voff, v0[0], v0[1], odd);   // :423
-                  } else if (gb + g < ng) {
+                    store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], odd, masked, active);
+                    if (a.tlev) store_pair<real>(w_dec, plane2, voff, coff, v0[0], v0[1], odd, masked, active);   // :423
+                  } else if (gb + g < ng && active) {
                     Q(a.lay_source)[o1] = vl[0];
                     if (a.tlev) Q(a.lev_source_dec)[o1] = v0[0];
                   }
@@ -644,15 +661,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int q = 0; q < 2; ++q) v1[q] = div_pi(ql1.w0 * b[0][q] + ql1.w1 * b[1][q], pi, rpi);
                   if (a.tlev) {                                                      // :424
-                    if (both) store_pair<real>(w_inc, plane2, voff, v1[0], v1[1], odd);
-                    else if (gb + g < ng) Q(a.lev_source_inc)[o1] = v1[0];
+                    if (both) store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
+                    else if (gb + g < ng && active) Q(a.lev_source_inc)[o1] = v1[0];
                   }
                 }
               }
             }
           });
         }
-      } else {
+        };
+        if (masked_wave) chunks(std::true_type{}); else chunks(std::false_type{});
+      } else if (lowest) {
         // ---- a lane of this wave is outside the staged rows: tables from global memory ----
         // (the indices go through an opaque asm: otherwise the 64-bit address arithmetic of this
         // rare path is speculated above the branch and paid by every tile)
@@ -711,7 +730,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       }
 
       // ---- surface source (:408-413), by the blocks of the first layer ----
-      if (MODE == MODE_LW && j == 0 && valid) {
+      if (MODE == MODE_LW && j == 0 && mine) {
         // (table rows from global memory: the surface temperature is not part of the window range)
         const PlPoint<real> qs = planck_point<real>(P(a.tsfc)[c], pt0, ud_pdt, ntp);
         const real *p0r = P(a.planck) + (long)qs.row * ng, *p1r = p0r + ng;

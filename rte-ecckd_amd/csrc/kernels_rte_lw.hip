@@ -44,7 +44,10 @@ namespace {
 #define ECCKD_LW_CW_F32 32
 #endif
 constexpr int kPF = ECCKD_LW_PF;   // prefetch depth in layers
-constexpr int kSchedSpan = 2;   // layers the instruction scheduler may interleave
+#ifndef ECCKD_LW_SPAN
+#define ECCKD_LW_SPAN 2
+#endif
+constexpr int kSchedSpan = ECCKD_LW_SPAN;   // layers the instruction scheduler may interleave
 
 template <typename real, int CW>
 __device__ __forceinline__ real gsum(real v) {
