@@ -370,9 +370,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     }
     __syncthreads();
 
-    // One round of global loads per tile, issued a tile ahead of its use and BEFORE the stores of
-    // the tile in flight: vector memory operations retire in order (one vmcnt), so a load issued
-    // after a tile's 64 stores would wait for every one of them to reach memory.
+    // The per-column inputs of a tile, one round of global loads.  (Loading them a tile ahead, before
+    // the stores of the tile in flight -- vector memory operations retire in order, so a load issued
+    // after a tile's 64 stores waits for all of them -- measured +1-2 % as long as the 26 extra VGPRs
+    // did not spill; with the slab-position logic in the kernel they do, and it measures -3 %.)
     real nx_p0, nx_p1, nx_T, nx_W[NB], nx_vlut, nx_Tl0 = real(0), nx_Tl1 = real(0);
     auto load_inputs = [&](long tile) {
       const long c = tile * kBlock + tid;
@@ -389,24 +390,14 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         nx_Tl1 = at(P(a.tlev) + (long)ncol * (j + 1));
       }
     };
-#ifndef ECCKD_FUSED_NO_PREFETCH
-    load_inputs(seg);
-    // complete them here (once per segment), so that inside the tile loop the only pending loads
-    // are the ones issued a tile ago
-    asm volatile("" : "+v"(nx_p0), "+v"(nx_p1), "+v"(nx_T), "+v"(nx_vlut), "+v"(nx_Tl0), "+v"(nx_Tl1));
-#pragma unroll
-    for (int s = 0; s < NB; ++s) asm volatile("" : "+v"(nx_W[s]));
-#endif
 
     for (long tile = seg; tile < seg_end; ++tile) {
       const long c = tile * kBlock + tid;
       const bool valid = c < ncol;
       const bool odd = (tid & 1) != 0;
       const long cc = c < ncol ? c : (long)ncol - 1;
-      // ---- setup: the inputs of this tile were loaded one tile ahead (see above) ----
-#ifdef ECCKD_FUSED_NO_PREFETCH
+      // ---- setup: one round of global loads ----
       load_inputs(tile);
-#endif
       const real p0 = nx_p0, p1 = nx_p1, Tlayer = nx_T;
       real W[NB];        // per-slot vmr, then weight (:143-149); 0 for unused slots
 #pragma unroll
@@ -420,9 +411,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       // position of the pass (with a single position: every existing column).
       const bool own = valid && ip0 >= pos_lo && ip0 <= pos_hi;
       if (!__any(own)) {   // nothing of this wave in this pass
-#ifndef ECCKD_FUSED_NO_PREFETCH
-        load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
-#endif
         continue;
       }
       const bool lowest = !__any(valid && ip0 < pos_lo);   // this is the pass of the wave's lowest lane
@@ -489,9 +477,6 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const bool masked_wave = !__all(active);
       const bool mine = slow_wave ? (lowest && valid) : active;   // lanes whose results this pass stores
       const int ip0_ = ip0, it0_ = it0, iv0_ = iv0;
-#ifndef ECCKD_FUSED_NO_PREFETCH
-      load_inputs(tile + 1 < seg_end ? tile + 1 : tile);
-#endif
 
       if (fast) {
         // The g-point work of a chunk is a static sequence of "items" of at most four 16-byte LDS
