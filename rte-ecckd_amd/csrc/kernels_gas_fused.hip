@@ -737,9 +737,6 @@ hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Chunk size: 8 g-points when ng is a multiple of 8, else 4 (rows are padded to a multiple of it).
-int pick_gc(int ng) { return ng % 8 == 0 ? 8 : 4; }
-
 int pick_nb(int nbil) {
   if (nbil <= 5) return 5;
   if (nbil <= 7) return 7;
