@@ -458,7 +458,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       bool inwin = true;
       if (MODE == MODE_LW) {
         qlay = planck_point<real>(Tlayer, pt0, ud_pdt, ntp);
-        ql0 = a.tlev ? planck_point<real>(Tl0, pt0, ud_pdt, ntp) : qlay;
+        // level j+1 serves lev_source_inc(:,j,:) AND lev_source_dec(:,j+1,:) (the same level: :419-424), so a
+        // block evaluates ONE level per layer; the top level (lev_source_dec of layer 1) is the extra
+        // work of the blocks of the first layer.
+        ql0 = (a.tlev && j == 0) ? planck_point<real>(Tl0, pt0, ud_pdt, ntp) : qlay;
         ql1 = a.tlev ? planck_point<real>(Tl1, pt0, ud_pdt, ntp) : qlay;
         const int rmin = min(qlay.row, min(ql0.row, ql1.row)), rmax = max(qlay.row, max(ql0.row, ql1.row));
         inwin = rmin >= pw_lo && rmax + 1 <= pw_lo + PW - 1;
@@ -483,7 +486,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         // reads (two consecutive g-points each):
         //   look_up_table gas : (g-pair, vmr plane h)   4 corner reads, 8 FMAs  -> partial / final od
         //   bilinear slot     : (slot, g-pair)          4 corner reads, 10 FMAs
-        //   Planck sources    : (g-pair, A|B)           A: layer + level j (4 reads), B: level j+1 (2)
+        //   Planck sources    : (g-pair)                layer + level j+1 (4 reads); first layer only: level j (2)
         // software-pipelined by hand: the reads of item i+1 are issued before the arithmetic of item
         // i.  Reads are volatile (kept in program order, never paired into ds_read2_b64) and every
         // item ends in an empty asm that pins its results, otherwise instruction selection floats
@@ -491,8 +494,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         // at 32 VGPRs.
         static_assert(GC % 4 == 0, "chunks are made of g-point pairs");
         constexpr int NP2 = GC / 2;                                  // g-pairs per chunk
-        constexpr int NLI = 2 * NP2, NBI = NB * NP2, NPI = (MODE == MODE_LW) ? 2 * NP2 : 0;
-        constexpr int NIT = NLI + NBI + NPI;
+        constexpr int NLI = 2 * NP2, NBI = NB * NP2;
         int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
         int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
         const int dPb = L.SB, dTb = R * L.SB;
@@ -508,13 +510,18 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         real *w_tau = Q(t.tau) + (long)ncol * j, *w_ssa = MODE == MODE_SW && t.ssa ? Q(t.ssa) + (long)ncol * j : nullptr;
         real *w_g = MODE == MODE_SW && t.ssa ? Q(t.g) + (long)ncol * j : nullptr;
         real *w_lay = MODE == MODE_LW ? Q(a.lay_source) + (long)ncol * j : nullptr;
-        real *w_dec = MODE == MODE_LW && a.tlev ? Q(a.lev_source_dec) + (long)ncol * j : nullptr;
+        const bool has_next = j + 1 < nlay;
+        real *w_dec0 = MODE == MODE_LW && a.tlev ? Q(a.lev_source_dec) + (long)ncol * j : nullptr;          // first layer
+        real *w_decn = MODE == MODE_LW && a.tlev ? Q(a.lev_source_dec) + (long)ncol * (j + 1) : nullptr;    // has_next
         real *w_inc = MODE == MODE_LW && a.tlev ? Q(a.lev_source_inc) + (long)ncol * j : nullptr;
         // Two copies of the chunk loop: with every lane owned (the common case) the stores are the
         // unconditional paired ones; the masked copy is for ragged waves and waves split between
         // slab positions.  A run-time flag instead costs a branch per store and ~2 % of the kernel.
-        auto chunks = [&](auto masked_c) __attribute__((always_inline)) {
+        auto chunks = [&](auto masked_c, auto first_c) __attribute__((always_inline)) {
         constexpr bool masked = decltype(masked_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;   // blocks of the first layer: the top level too
+        constexpr int NPI = (MODE == MODE_LW) ? (FIRST ? 2 * NP2 : NP2) : 0;
+        constexpr int NIT = NLI + NBI + NPI;
         for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
           real acc[GC];
           if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
@@ -550,14 +557,16 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
               double2_t *b = buf[it & 1];
               const int o = ob + s * ngp + g;
               b[0] = ld2(o); b[1] = ld2(o + dPb); b[2] = ld2(o + dTb); b[3] = ld2(o + dTb + dPb);
-            } else if constexpr (it < NIT) {                // Planck sources of one g-pair, half A or B
-              const int k = it - NLI - NBI, g = 2 * (k / 2);
+            } else if constexpr (it < NIT) {                // Planck sources of one g-pair
+              constexpr int k = it - NLI - NBI;
               double2_t *b = buf[it & 1];
-              if ((k & 1) == 0) {
+              if constexpr (k < NP2) {                      // layer and level j+1
+                const int g = 2 * k;
                 b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
-                b[2] = ld2(pb + ql0.off + g);  b[3] = ld2(pb + ql0.off + L.SP + g);
-              } else {
-                b[0] = ld2(pb + ql1.off + g);  b[1] = ld2(pb + ql1.off + L.SP + g);
+                b[2] = ld2(pb + ql1.off + g);  b[3] = ld2(pb + ql1.off + L.SP + g);
+              } else {                                      // first layer: level j
+                const int g = 2 * (k - NP2);
+                b[0] = ld2(pb + ql0.off + g);  b[1] = ld2(pb + ql0.off + L.SP + g);
               }
             }
             // ---------------- arithmetic of item `it - 1` ----------------
@@ -624,30 +633,37 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   }
                 }
               } else {
-                const int k = pi_ - NLI - NBI, g = 2 * (k / 2);
+                constexpr int k = pi_ - NLI - NBI;
+                constexpr int g = 2 * (k < NP2 ? k : k - NP2);
                 const bool both = FULL || gb + g + 1 < ng;
                 const long o1 = c + (long)ncol * (j + (long)nlay * (gb + g));   // odd ng: last g-point alone
-                if ((k & 1) == 0) {
-                  real vl[2], v0[2];
+                if constexpr (k < NP2) {
+                  real vl[2], v1[2];
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
                     vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
-                    v0[q] = div_pi(ql0.w0 * b[2][q] + ql0.w1 * b[3][q], pi, rpi);
+                    v1[q] = div_pi(ql1.w0 * b[2][q] + ql1.w1 * b[3][q], pi, rpi);
                   }
                   if (both) {
                     store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], odd, masked, active);
-                    if (a.tlev) store_pair<real>(w_dec, plane2, voff, coff, v0[0], v0[1], odd, masked, active);   // :423
+                    if (a.tlev) {                                                    // :423-424
+                      store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
+                      if (has_next) store_pair<real>(w_decn, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
+                    }
                   } else if (gb + g < ng && active) {
                     Q(a.lay_source)[o1] = vl[0];
-                    if (a.tlev) Q(a.lev_source_dec)[o1] = v0[0];
+                    if (a.tlev) {
+                      Q(a.lev_source_inc)[o1] = v1[0];
+                      if (has_next) Q(a.lev_source_dec)[o1 + ncol] = v1[0];
+                    }
                   }
                 } else {
-                  real v1[2];
+                  real v0[2];
 #pragma unroll
-                  for (int q = 0; q < 2; ++q) v1[q] = div_pi(ql1.w0 * b[0][q] + ql1.w1 * b[1][q], pi, rpi);
-                  if (a.tlev) {                                                      // :424
-                    if (both) store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
-                    else if (gb + g < ng && active) Q(a.lev_source_inc)[o1] = v1[0];
+                  for (int q = 0; q < 2; ++q) v0[q] = div_pi(ql0.w0 * b[0][q] + ql0.w1 * b[1][q], pi, rpi);
+                  if (a.tlev) {
+                    if (both) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], odd, masked, active);
+                    else if (gb + g < ng && active) Q(a.lev_source_dec)[o1] = v0[0];
                   }
                 }
               }
@@ -655,7 +671,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
           });
         }
         };
-        if (masked_wave) chunks(std::true_type{}); else chunks(std::false_type{});
+        if (j == 0) {
+          if (masked_wave) chunks(std::true_type{}, std::true_type{}); else chunks(std::false_type{}, std::true_type{});
+        } else {
+          if (masked_wave) chunks(std::true_type{}, std::false_type{}); else chunks(std::false_type{}, std::false_type{});
+        }
       } else if (lowest) {
         // ---- a lane of this wave is outside the staged rows: tables from global memory ----
         // (the indices go through an opaque asm: otherwise the 64-bit address arithmetic of this
@@ -705,9 +725,12 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
             if (MODE == MODE_LW) {
               const real *pg = P(a.planck) + g;   // table rows from global memory: any row, staged or not
               Q(a.lay_source)[o] = div_pi(qlay.w0 * pg[(long)qlay.row * ng] + qlay.w1 * pg[(long)(qlay.row + 1) * ng], pi, rpi);
-              if (a.tlev) {
-                Q(a.lev_source_dec)[o] = div_pi(ql0.w0 * pg[(long)ql0.row * ng] + ql0.w1 * pg[(long)(ql0.row + 1) * ng], pi, rpi);
-                Q(a.lev_source_inc)[o] = div_pi(ql1.w0 * pg[(long)ql1.row * ng] + ql1.w1 * pg[(long)(ql1.row + 1) * ng], pi, rpi);
+              if (a.tlev) {   // level j+1 -> inc of this layer and dec of the next; the top level by the first layer
+                const real v1 = div_pi(ql1.w0 * pg[(long)ql1.row * ng] + ql1.w1 * pg[(long)(ql1.row + 1) * ng], pi, rpi);
+                Q(a.lev_source_inc)[o] = v1;
+                if (j + 1 < nlay) Q(a.lev_source_dec)[o + ncol] = v1;
+                if (j == 0)
+                  Q(a.lev_source_dec)[o] = div_pi(ql0.w0 * pg[(long)ql0.row * ng] + ql0.w1 * pg[(long)(ql0.row + 1) * ng], pi, rpi);
               }
             }
           }
