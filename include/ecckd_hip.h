@@ -172,6 +172,22 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
                  const int *band2gpt, const double *sfc_emis, double *flux_up, double *flux_dn,
                  int memspace, void *stream);
 
+/* ecckd_rte_lw for level sources that hold ONE value per level:
+ *     lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:)   for l = 1 .. nlay-1.
+ * That is what ecckd_gas_optics_lw writes (src/gas_optics_ecckd.f90:419-424: both arrays are slices
+ * of one (ncol,nlay+1,ngpt) buffer), but it is NOT part of RTE-RRTMGP's rte_lw contract (RRTMGP's
+ * own gas optics fills the two arrays with different values), so the caller has to assert it by
+ * calling this entry point.  The solver then reads each level once (24 instead of 32 B/cell): the
+ * array that holds the far edge of the layers in walking order (lev_source_inc when top_at_1) in
+ * full, the other one for the first layer only.  Same arithmetic and the same fluxes, bit for bit,
+ * as ecckd_rte_lw when the assertion holds.  Same arguments. */
+int ecckd_rte_lw_shared_levels(int device, int ncol, int nlay, int ngpt, int top_at_1,
+                               int n_gauss_angles, const double *tau, const double *lay_source,
+                               const double *lev_source_inc, const double *lev_source_dec,
+                               const double *sfc_source, int nband, const int *band2gpt,
+                               const double *sfc_emis, double *flux_up, double *flux_dn,
+                               int memspace, void *stream);
+
 /* Single-precision flavour of ecckd_rte_lw. */
 int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
                      const float *tau, const float *lay_source, const float *lev_source_inc,

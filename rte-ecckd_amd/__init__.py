@@ -327,6 +327,7 @@ class SourceFuncLW:
 
     def __init__(self):
         self.lay_source = self.lev_source_inc = self.lev_source_dec = self.sfc_source = None
+        self.levels_shared = False   # True after ecckd's gas_optics: one value per level (:419-424)
 
     def alloc(self, ncol, nlay, spectral_desc, like=None):
         ng = spectral_desc.get_ngpt()
@@ -538,6 +539,7 @@ class GasOpticsEcckd:
                 P(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
                 P(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
                 P(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
+        sources.levels_shared = rc == 0 and tlev is not None
         return last_error() if rc else ""
 
     def gas_optics_ext(self, play, plev, tlay, gas_desc, optical_props, toa_src, col_dry=None):
@@ -567,17 +569,22 @@ def _device_of(a):
     return 0
 
 
-def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1, device=None):
+def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1, device=None,
+           shared_levels=False):
     """``rte_lw(optical_props, top_at_1, sources, sfc_emis(nband,ncol), fluxes, n_gauss_angles=)``
     (ecckd_rfmip_lw.F90:130-135).  ``sfc_emis`` is ``(ncol, nband)`` in numpy order.  float32 arrays
-    take the single-precision entry point."""
+    take the single-precision entry point.  ``shared_levels=True`` asserts that the level sources hold
+    one value per level (``sources.levels_shared``, set by ecckd's gas_optics) and takes
+    ``ecckd_rte_lw_shared_levels`` (fp64 only)."""
     ng, nlay, ncol = optical_props.tau.shape
     b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
     nband = b2g.shape[0]
     f32 = _is_f32(optical_props.tau)
     space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, fluxes.flux_up, fluxes.flux_dn])
     dev = _device_of(optical_props.tau) if device is None else device
-    fn = lib().ecckd_rte_lw_f32 if f32 else lib().ecckd_rte_lw
+    if shared_levels and f32:
+        return "rte_lw: shared_levels is implemented for float64 arrays"
+    fn = lib().ecckd_rte_lw_f32 if f32 else (lib().ecckd_rte_lw_shared_levels if shared_levels else lib().ecckd_rte_lw)
     P = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
     rc = fn(int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), P(optical_props.tau),
             P(sources.lay_source, (ng, nlay, ncol), "lay_source"),

@@ -66,6 +66,7 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // helper below sizes its copies with esz() and the kernels are launched with f32 = 1.  Data pointers
 // keep their `double *` static type on the way through (they are only passed on, never indexed).
 thread_local int g_f32 = 0;
+thread_local int g_shared_levels = 0;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
 struct PlanRecord {
   int npass = 0, first_fused = 0, planck_fused = 0;
@@ -807,6 +808,7 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
   a.nband = nband;
   a.f32 = g_f32;
+  a.shared_levels = g_shared_levels;
   for (int k = 0; k < n_gauss_angles; ++k) {
     a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
     a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
@@ -864,6 +866,19 @@ int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int
   return ecckd_rte_lw(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, c(tau), c(lay_source), c(lev_source_inc),
                       c(lev_source_dec), c(sfc_source), nband, band2gpt, c(sfc_emis), w(flux_up), w(flux_dn),
                       memspace, stream);
+}
+
+int ecckd_rte_lw_shared_levels(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                               const double *tau, const double *lay_source, const double *lev_source_inc,
+                               const double *lev_source_dec, const double *sfc_source, int nband,
+                               const int *band2gpt, const double *sfc_emis, double *flux_up, double *flux_dn,
+                               int memspace, void *stream) {
+  struct Scope {
+    Scope() { g_shared_levels = 1; }
+    ~Scope() { g_shared_levels = 0; }
+  } scope;
+  return ecckd_rte_lw(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, tau, lay_source, lev_source_inc,
+                      lev_source_dec, sfc_source, nband, band2gpt, sfc_emis, flux_up, flux_dn, memspace, stream);
 }
 
 int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,

@@ -97,6 +97,7 @@ struct RteLwArgs {
   double *flux_up, *flux_dn;
   double *scratch;             // generic-nlay path only
   int f32;                     // 1: the data pointers address float arrays
+  int shared_levels;           // 1: lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:): each level is read once
 };
 
 struct RteSwArgs {

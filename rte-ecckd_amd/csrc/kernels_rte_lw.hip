@@ -29,6 +29,11 @@
 // NL > 0, OVER: nlay > NL.  The bottom NL layers run from registers as above; trans/source_up of
 //   the top nlay - NL layers go through a per-wave global scratch ring (16 B/cell written and read
 //   back for those layers only).
+// SHARED: the caller asserts that the two level-source arrays describe ONE value per level,
+//   lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:) -- what ecckd's gas optics produces
+//   (src/gas_optics_ecckd.f90:419-424: both are slices of one buffer).  The source at the far edge
+//   of a layer is then the near-edge source of the next one: it is carried in a register and only
+//   the first layer reads the second array (24 instead of 32 B/cell).  Same arithmetic, same bits.
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -75,7 +80,7 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #endif
 }
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER>
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   static_assert(NL > 0 && !(EXACT && OVER), "unrolled layer count; overflow only in the padded form");
   constexpr int GW = 64 / CW;
@@ -129,7 +134,9 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       sT = Q(a.scratch) + ((long)blockIdx.x * 2 * nover) * 64 + lane;
       sSU = sT + (long)nover * 64;
     }
-    real ptau[kPF], play[kPF], pbdn[kPF], pbup[kPF];
+    real ptau[kPF], play[kPF], pbdn[kPF];
+    [[maybe_unused]] real pbup[SHARED ? 1 : kPF];
+    [[maybe_unused]] real bup_first = real(0);   // SHARED: near-edge source of the first register-resident layer
 
     // Element offset of the next layer to prefetch.  It is advanced step by step and made
     // opaque to the optimiser after every advance: otherwise the fully unrolled layer loop is
@@ -141,6 +148,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       const int gg = g < ng ? g : ng - 1;
       qn = cc + (long)ncol * nlay * gg + (long)ncol * (lay0 + lstep * nover);
       asm volatile("" : "+v"(qn));
+      if (SHARED && !OVER) bup_first = __builtin_nontemporal_load(Bup + qn);
     };
     // `sl` = layer being requested (compile-time in the unrolled code); in the padded variants the
     // offset stops advancing at the last real layer, so absent layers re-read it (finite data).
@@ -149,12 +157,12 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       ptau[slot] = __builtin_nontemporal_load(P(a.tau) + qn);
       play[slot] = __builtin_nontemporal_load(P(a.lay_source) + qn);
       pbdn[slot] = __builtin_nontemporal_load(Bdn + qn);
-      pbup[slot] = __builtin_nontemporal_load(Bup + qn);
+      if (!SHARED) pbup[slot] = __builtin_nontemporal_load(Bup + qn);
 #else
       ptau[slot] = P(a.tau)[qn];
       play[slot] = P(a.lay_source)[qn];
       pbdn[slot] = Bdn[qn];
-      pbup[slot] = Bup[qn];
+      if (!SHARED) pbup[slot] = Bup[qn];
 #endif
       if (!PAD || present(abs_layer(sl + 1))) qn += qstep;
       asm volatile("" : "+v"(qn));
@@ -206,20 +214,26 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         acc_add(&acc_dn[(act ? s : nlev) * CW + cl], v, owner);
         I = t * I + sdn;
       };
+      [[maybe_unused]] real carry = bup_first;   // SHARED: far-edge source of the layer above
       if constexpr (OVER) {   // the layers above the register-resident ones: plain loads, scratch ring
         for (int s = 0; s < nover; ++s) {
           const long q = base + (long)ncol * (lay0 + lstep * s);
+          const real bdn = Bdn[q];
+          const real bup = (SHARED && s > 0) ? carry : Bup[q];
           real t, su;
-          layer(s, P(a.tau)[q], P(a.lay_source)[q], Bdn[q], Bup[q], t, su);
+          layer(s, P(a.tau)[q], P(a.lay_source)[q], bdn, bup, t, su);
+          carry = bdn;
           sT[(long)s * 64] = t;
           sSU[(long)s * 64] = su;
         }
       }
 #pragma unroll
       for (int s = 0; s < NL; ++s) {
-        const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF], bup = pbup[s % kPF];
+        const real tau = ptau[s % kPF], lay = play[s % kPF], bdn = pbdn[s % kPF];
+        const real bup = SHARED ? carry : pbup[s % kPF];
         if (s + kPF < NL) issue_after(s % kPF, s + kPF, I);
         layer(abs_layer(s), tau, lay, bdn, bup, T[s], SU[s]);
+        if (SHARED) carry = bdn;
         if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
       }
       // the next pair's first register-resident layers start streaming while the up sweep runs
@@ -265,9 +279,9 @@ constexpr int kOverWaves = 2048;   // grid of the overflow variant (its scratch 
 constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
 constexpr int kOverCW = 16;   // 16 * (nlay + 2) * CW bytes of LDS accumulators per wave: 16 columns keep 4 waves per CU
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER>
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER>;
+  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER, SHARED>;
   const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + (EXACT ? 0 : 1)) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -279,16 +293,16 @@ hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename real>
+template <typename real, bool SHARED>
 hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
   constexpr int CW = sizeof(real) == 8 ? ECCKD_LW_CW : ECCKD_LW_CW_F32;
-  if (a.nlay == 60) return launch_one<real, 60, CW, true, false>(a, s);
-  if (a.nlay <= 32) return launch_one<real, 32, CW, false, false>(a, s);
-  if (a.nlay <= 48) return launch_one<real, 48, CW, false, false>(a, s);
-  if (a.nlay <= 64) return launch_one<real, 64, CW, false, false>(a, s);
-  if (a.nlay <= 80) return launch_one<real, 80, CW, false, false>(a, s);
-  if (a.nlay <= kMaxRegisterLayers) return launch_one<real, 96, CW, false, false>(a, s);
-  return launch_one<real, 96, kOverCW, false, true>(a, s);
+  if (a.nlay == 60) return launch_one<real, 60, CW, true, false, SHARED>(a, s);
+  if (a.nlay <= 32) return launch_one<real, 32, CW, false, false, SHARED>(a, s);
+  if (a.nlay <= 48) return launch_one<real, 48, CW, false, false, SHARED>(a, s);
+  if (a.nlay <= 64) return launch_one<real, 64, CW, false, false, SHARED>(a, s);
+  if (a.nlay <= 80) return launch_one<real, 80, CW, false, false, SHARED>(a, s);
+  if (a.nlay <= kMaxRegisterLayers) return launch_one<real, 96, CW, false, false, SHARED>(a, s);
+  return launch_one<real, 96, kOverCW, false, true, SHARED>(a, s);
 }
 
 }  // namespace
@@ -304,7 +318,8 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   static_assert(kPF <= 32, "prefetch ring deeper than the smallest unrolled layer count");
-  return a.f32 ? launch_real<float>(a, s) : launch_real<double>(a, s);
+  if (a.shared_levels) return a.f32 ? launch_real<float, true>(a, s) : launch_real<double, true>(a, s);
+  return a.f32 ? launch_real<float, false>(a, s) : launch_real<double, false>(a, s);
 }
 
 }  // namespace ecckd

@@ -103,7 +103,9 @@ program ecckd_driver
       call stop_on_err(op1%alloc_1scl(nc, nlay, ecckd))
       call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), tsfc(c0:c1), gas_concs, &
                                         op1, source, tlev=tlev(c0:c1, :)))
-      call stop_on_err(rte_lw(op1, top_at_1, source, sfc_spec, fluxes, n_gauss_angles=n_quad_angles))
+      ! ecckd level sources hold one value per level (src/gas_optics_ecckd.f90:419-424): each level is read once
+      call stop_on_err(rte_lw(op1, top_at_1, source, sfc_spec, fluxes, n_gauss_angles=n_quad_angles, &
+                              lev_sources_shared=.true.))
     else
       if (allocated(sfc_spec2)) deallocate(sfc_spec2, toa)
       allocate(sfc_spec2(nbnd, nc), toa(nc, ecckd%get_ngpt()))

@@ -25,9 +25,21 @@ module mo_rte_lw
       type(c_ptr), value :: stream
       integer(c_int) :: rc
     end function c_rte_lw
+    function c_rte_lw_shared(device, ncol, nlay, ngpt, top_at_1, nmus, tau, lay_source, lev_inc, lev_dec, sfc_source, &
+                      nband, band2gpt, sfc_emis, flux_up, flux_dn, memspace, stream) &
+        bind(C, name="ecckd_rte_lw_shared_levels") result(rc)
+      import c_int, c_double, c_ptr
+      integer(c_int), value :: device, ncol, nlay, ngpt, top_at_1, nmus, nband, memspace
+      real(c_double), dimension(*), intent(in) :: tau, lay_source, lev_inc, lev_dec, sfc_source, sfc_emis
+      integer(c_int), dimension(*), intent(in) :: band2gpt
+      real(c_double), dimension(*), intent(inout) :: flux_up, flux_dn
+      type(c_ptr), value :: stream
+      integer(c_int) :: rc
+    end function c_rte_lw_shared
   end interface
 contains
-  function rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles, device) result(error_msg)
+  function rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles, device, lev_sources_shared) &
+      result(error_msg)
     class(ty_optical_props_arry), intent(in) :: optical_props
     logical, intent(in) :: top_at_1
     type(ty_source_func_lw), intent(in) :: sources
@@ -35,8 +47,12 @@ contains
     type(ty_fluxes_broadband), intent(inout) :: fluxes
     integer, optional, intent(in) :: n_gauss_angles
     integer, optional, intent(in) :: device
+    !> .true.: lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:), as ecckd's gas_optics writes them
+    !> (src/gas_optics_ecckd.f90:419-424); each level is then read once (ecckd_rte_lw_shared_levels)
+    logical, optional, intent(in) :: lev_sources_shared
     character(len=128) :: error_msg
     integer :: ncol, nlay, ngpt, nmus, dev
+    logical :: shared
     integer(c_int) :: rc
     real(wp), dimension(:,:), allocatable :: up, dn
     error_msg = ""
@@ -56,11 +72,21 @@ contains
       return
     end if
     allocate(up(ncol, nlay + 1), dn(ncol, nlay + 1))
-    rc = c_rte_lw(int(dev, c_int), int(ncol, c_int), int(nlay, c_int), int(ngpt, c_int), &
-                  merge(1_c_int, 0_c_int, top_at_1), int(nmus, c_int), optical_props%tau, sources%lay_source, &
-                  sources%lev_source_inc, sources%lev_source_dec, sources%sfc_source, &
-                  int(optical_props%get_nband(), c_int), int(optical_props%get_band_lims_gpoint(), c_int), &
-                  sfc_emis, up, dn, 0_c_int, c_null_ptr)
+    shared = .false.
+    if (present(lev_sources_shared)) shared = lev_sources_shared
+    if (shared) then
+      rc = c_rte_lw_shared(int(dev, c_int), int(ncol, c_int), int(nlay, c_int), int(ngpt, c_int), &
+                           merge(1_c_int, 0_c_int, top_at_1), int(nmus, c_int), optical_props%tau, sources%lay_source, &
+                           sources%lev_source_inc, sources%lev_source_dec, sources%sfc_source, &
+                           int(optical_props%get_nband(), c_int), int(optical_props%get_band_lims_gpoint(), c_int), &
+                           sfc_emis, up, dn, 0_c_int, c_null_ptr)
+    else
+      rc = c_rte_lw(int(dev, c_int), int(ncol, c_int), int(nlay, c_int), int(ngpt, c_int), &
+                    merge(1_c_int, 0_c_int, top_at_1), int(nmus, c_int), optical_props%tau, sources%lay_source, &
+                    sources%lev_source_inc, sources%lev_source_dec, sources%sfc_source, &
+                    int(optical_props%get_nband(), c_int), int(optical_props%get_band_lims_gpoint(), c_int), &
+                    sfc_emis, up, dn, 0_c_int, c_null_ptr)
+    end if
     if (rc /= 0) then
       error_msg = c_error_message()
       return

@@ -268,6 +268,55 @@ def test_rte_lw_other_layer_counts_and_orientation(pkg, gpu, oracle_mod, nlay, t
     assert np.array_equal(fl2.flux_up, fl.flux_up.cpu().numpy())
 
 
+@pytest.mark.parametrize("nlay,top_at_1,nmus", [(60, True, 1), (60, False, 3), (33, True, 2), (96, False, 1), (137, True, 1)])
+def test_rte_lw_shared_levels_is_bit_identical(pkg, gpu, nlay, top_at_1, nmus):
+    """ecckd_rte_lw_shared_levels (one value per level, read once) against ecckd_rte_lw on level sources that do
+    hold one value per level -- lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:), as ecckd's gas optics writes
+    them (src/gas_optics_ecckd.f90:419-424): the same fluxes bit for bit, in every solver variant."""
+    import torch
+    rng = np.random.default_rng(1000 + nlay)
+    ng, ncol = 6, 200
+    tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay = rng.uniform(1, 9, (ng, nlay, ncol))
+    lev = rng.uniform(1, 9, (ng, nlay + 1, ncol))
+    inc, dec = np.ascontiguousarray(lev[:, 1:]), np.ascontiguousarray(lev[:, :-1])
+    sfc = rng.uniform(1, 9, (ng, ncol))
+    emis = rng.uniform(0.7, 1.0, (ncol, 1))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    out = []
+    for shared in (False, True):
+        fl = pkg.FluxesBroadband(torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu),
+                                 torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu))
+        assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus, shared_levels=shared) == ""
+        out.append((fl.flux_up.cpu().numpy(), fl.flux_dn.cpu().numpy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.all(out[0][0] > 0)
+
+
+def test_gas_optics_marks_its_level_sources_as_shared(pkg, gpu, lw):
+    import torch
+    k, m = lw
+    cols = synthetic.columns(9, 130, k.get_press_min())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    gc = helpers.product_gas_concs(pkg, cols, to=t)
+    plev = t(cols["plev"])
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(130, 60, k, like=plev)
+    src = pkg.SourceFuncLW(); src.alloc(130, 60, k, like=plev)
+    assert not src.levels_shared
+    assert k.gas_optics(None, plev, t(cols["tlay"]), t(cols["tsfc"]), gc, op, src, tlev=t(cols["tlev"])) == ""
+    assert src.levels_shared
+    assert torch.equal(src.lev_source_inc[:, :-1], src.lev_source_dec[:, 1:])       # the property itself
+    fl = [pkg.FluxesBroadband(torch.zeros((61, 130), dtype=torch.float64, device=gpu),
+                              torch.zeros((61, 130), dtype=torch.float64, device=gpu)) for _ in range(2)]
+    emis = t(cols["sfc_emis"][:, None])
+    assert pkg.rte_lw(op, True, src, emis, fl[0]) == ""
+    assert pkg.rte_lw(op, True, src, emis, fl[1], shared_levels=src.levels_shared) == ""
+    assert torch.equal(fl[0].flux_up, fl[1].flux_up) and torch.equal(fl[0].flux_dn, fl[1].flux_dn)
+
+
 def test_lw_36g_16band_model(pkg, gpu, oracle_mod):
     """The higher-g-point LW file present in the reference (rrtmgp-tol0.061: 36 g, 16 bands)."""
     import torch
