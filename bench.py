@@ -213,7 +213,7 @@ def main():
         roofline = None
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01g_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01h_hbm_traffic.json")))
             if ncol == 1000000 and args.dtype == "f64" and args.lut == "fsck" and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
@@ -222,7 +222,7 @@ def main():
             ach = per_kernel[dom]["GBps"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": "profiles/r01g_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                        "traffic_source": "profiles/r01h_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                           "gfx950-corrected)" if traffic else None,
                         "avg_launch_ms": per_kernel[dom]["avg_ms"],
                         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes_per_launch"]}
