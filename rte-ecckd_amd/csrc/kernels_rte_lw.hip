@@ -318,7 +318,7 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   static_assert(kPF <= 32, "prefetch ring deeper than the smallest unrolled layer count");
-  if (a.shared_levels) return a.f32 ? launch_real<float, true>(a, s) : launch_real<double, true>(a, s);
+  if (a.shared_levels && !a.f32) return launch_real<double, true>(a, s);   // (no single-precision entry point sets it)
   return a.f32 ? launch_real<float, false>(a, s) : launch_real<double, false>(a, s);
 }
 
