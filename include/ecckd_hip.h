@@ -227,6 +227,8 @@ int ecckd_gas_optics_plan(const ecckd_model_t *model, int ncol, int nlay, int si
  *   1           reference order: every product and sum in the order the Fortran expressions
  *               spell, no FMA contraction, gases accumulated in gas_desc order (:370).  tau then
  *               differs from an IEEE evaluation of the reference only through the device log().
+ *   The shortwave solver follows the mode too: 0 evaluates its three reciprocals per cell with
+ *   v_rcp_f64 + two Newton steps (~1 ulp), 1 with IEEE division.
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_arithmetic(int mode);
 int ecckd_get_arithmetic(void);

@@ -894,6 +894,7 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (check_device(device)) return 1;
   if (ncol == 0) return 0;
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nband = nband;
+  a.exact_division = g_arith != 0;
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
   Arena &sa = g_scratch_arena[device];

@@ -108,6 +108,7 @@ struct RteSwArgs {
   unsigned char gpt2band[256];
   double *flux_up, *flux_dn, *flux_dir;   // flux_dir may be nullptr
   double *scratch;
+  int exact_division;          // 1 (reference-order arithmetic mode): IEEE `/`; 0: reciprocal + Newton steps
 };
 
 // Host-side helpers -------------------------------------------------------------------------

@@ -51,6 +51,18 @@ __device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
 // sw_two_stream for one cell: Zdunkowski PIFM coefficients, diffuse and direct reflectance and
 // transmittance, direct-beam transmittance.
 struct TwoStream { double Rdif, Tdif, Rdir, Tdir, Tnoscat; };
+// 1/x: the IEEE division sequence (~15 instructions) in the reference-order arithmetic mode; in the fast
+// mode v_rcp_f64 and two Newton steps (~1 ulp, 6 instructions).  The solver is bound by fp64 issue:
+// -8.5 % on the kernel, fluxes unchanged to 1e-11 W m-2.
+template <bool FAST>
+__device__ __forceinline__ double rcp(double x) {
+  if (!FAST) return 1. / x;
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.), r, r);
+  r = fma(fma(-x, r, 1.), r, r);
+  return r;
+}
+template <bool FAST>
 __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq, double mu0, double mu0_inv) {
   const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
   const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
@@ -63,14 +75,15 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
   const double k = sqrt(kk0 > 1.e-12 ? kk0 : 1.e-12);
   const double exp_minusktau = exp(-tau * k);
   const double exp_minus2ktau = exp_minusktau * exp_minusktau;
-  double RT_term = 1. / (k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
+  double RT_term = rcp<FAST>(k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
   TwoStream r;
   r.Rdif = RT_term * gamma2 * (1. - exp_minus2ktau);
   r.Tdif = RT_term * 2. * k * exp_minusktau;
   r.Tnoscat = exp(-tau * mu0_inv);
   const double k_mu = k * mu0, k_gamma3 = k * gamma3, k_gamma4 = k * gamma4;
   const double d = 1. - k_mu * k_mu;
-  RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
+  if (FAST) RT_term = w0 * RT_term * rcp<true>(fabs(d) >= eps ? d : eps);
+  else RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
   r.Rdir = RT_term * ((1. - k_mu) * (alpha2 + k_gamma3) - (1. + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
                       2.0 * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * r.Tnoscat);
   r.Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * r.Tnoscat -
@@ -85,7 +98,7 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
 // needs as well (24 + 48 + 48 = 120 B/cell).  The kernel is bound by that traffic, not by the
 // arithmetic (0.25 VALU wave-instr/clk/CU of 0.81 available at this occupancy): measured 4.52 ms
 // stored vs 3.85 ms recomputed per 1e5 columns x 27 g-points (recomputed: 52 % of the fp64 VALU rate).
-template <int CW, bool RECOMPUTE>
+template <int CW, bool RECOMPUTE, bool FAST>
 __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   constexpr int GW = 64 / CW;
   extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
@@ -146,8 +159,8 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
           const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
           ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
         }
-        const TwoStream ts = two_stream(ctau, cssa, cg, mu0, mu0_inv);
-        const double denom = 1. / (1. - ts.Rdif * albedo);                           // adding, Eq 10
+        const TwoStream ts = two_stream<FAST>(ctau, cssa, cg, mu0, mu0_inv);
+        const double denom = rcp<FAST>(1. - ts.Rdif * albedo);                             // adding, Eq 10
         if (!RECOMPUTE) {
           sA[64L * s] = ts.Tdif * denom;
           sB[64L * s] = ts.Rdif * denom;
@@ -199,8 +212,8 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
         }
         double A, B, C, Tn;
         if (RECOMPUTE) {
-          const TwoStream ts = two_stream(ctau, cssa, cg, mu0, mu0_inv);
-          const double denom = 1. / (1. - ts.Rdif * alb_next);   // the same expression as in pass 1: same bits
+          const TwoStream ts = two_stream<FAST>(ctau, cssa, cg, mu0, mu0_inv);
+          const double denom = rcp<FAST>(1. - ts.Rdif * alb_next);     // the same expression as in pass 1: same bits
           A = ts.Tdif * denom; B = ts.Rdif * denom; C = ts.Tdir * denom; Tn = ts.Tnoscat;
         } else {
           A = sA[64L * s]; B = sB[64L * s]; C = sC[64L * s]; Tn = sTn[64L * s];
@@ -246,7 +259,7 @@ size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   constexpr int CW = ECCKD_SW_CW;
-  auto k = rte_sw_kernel<CW, kSwRecompute>;
+  auto k = a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false> : rte_sw_kernel<CW, kSwRecompute, true>;
   const size_t lds = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
