@@ -203,6 +203,23 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
                  int memspace, void *stream);
 
+/* Spectral (per-band) fluxes: what RTE-RRTMGP callers get by passing a ty_fluxes_byband to rte_lw /
+ * rte_sw instead of the ty_fluxes_broadband the reference drivers use (ecckd_rfmip_lw.F90:108-109).
+ * bnd_flux_*(ncol,nlay+1,nband) = sum over the g-points of each band (one solver pass per band over its
+ * contiguous g-points); flux_up / flux_dn / flux_dir (ncol,nlay+1) are optional (NULL) and hold the sum over
+ * bands.  Other arguments as ecckd_rte_lw / ecckd_rte_sw; fp64. */
+int ecckd_rte_lw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                        const double *tau, const double *lay_source, const double *lev_source_inc,
+                        const double *lev_source_dec, const double *sfc_source, int nband,
+                        const int *band2gpt, const double *sfc_emis, double *bnd_flux_up,
+                        double *bnd_flux_dn, double *flux_up, double *flux_dn, int memspace, void *stream);
+int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
+                        const double *ssa, const double *g, const double *mu0, const double *toa_flux,
+                        int nband, const int *band2gpt, const double *sfc_alb_dir,
+                        const double *sfc_alb_dif, double *bnd_flux_up, double *bnd_flux_dn,
+                        double *bnd_flux_dir, double *flux_up, double *flux_dn, double *flux_dir,
+                        int memspace, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Launch plan of a gas_optics call (no counterpart in the reference; works on host-only models,
  * device -1, and launches nothing): how the library would run gas_optics for this model, gas list

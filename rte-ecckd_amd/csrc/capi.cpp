@@ -66,7 +66,9 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // helper below sizes its copies with esz() and the kernels are launched with f32 = 1.  Data pointers
 // keep their `double *` static type on the way through (they are only passed on, never indexed).
 thread_local int g_f32 = 0;
-thread_local int g_shared_levels = 0;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
+thread_local int g_shared_levels = 0;
+// set by the *_byband entry points around the per-band solver calls: band of every g-point of the sub-range
+thread_local int g_band_override = -1;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
 struct PlanRecord {
   int npass = 0, first_fused = 0, planck_fused = 0;
@@ -802,7 +804,8 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   if (!tau || !lay_source || !lev_source_inc || !lev_source_dec || !sfc_source || !sfc_emis || !flux_up || !flux_dn)
     return fail("ecckd_rte_lw: null argument");
   ecckd::RteLwArgs a{};
-  if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
+  if (g_band_override >= 0) std::memset(a.gpt2band, g_band_override, sizeof a.gpt2band);
+  else if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
   if (check_device(device)) return 1;
   if (ncol == 0) return 0;
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
@@ -890,7 +893,8 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (!tau || !ssa || !g || !mu0 || !toa_flux || !sfc_alb_dir || !sfc_alb_dif || !flux_up || !flux_dn)
     return fail("ecckd_rte_sw: null argument");
   ecckd::RteSwArgs a{};
-  if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
+  if (g_band_override >= 0) std::memset(a.gpt2band, g_band_override, sizeof a.gpt2band);
+  else if (fill_band_map(ngpt, nband, band2gpt, a.gpt2band)) return 1;
   if (check_device(device)) return 1;
   if (ncol == 0) return 0;
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nband = nband;
@@ -936,6 +940,79 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   if (flux_dir && d2h(flux_dir, d_dir, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- spectral (per-band) fluxes: ty_fluxes_byband of RTE-RRTMGP ----
+namespace {
+struct BandScope {
+  explicit BandScope(int b) { g_band_override = b; }
+  ~BandScope() { g_band_override = -1; }
+};
+// out(:) = sum over planes of planes(:, b), on the device or on the host
+int sum_planes(const double *planes, int nplanes, size_t n, double *out, int memspace, void *stream) {
+  if (memspace == ECCKD_DEVICE) {
+    HIPCHK(ecckd::launch_sum_planes(planes, nplanes, n, out, g_f32, static_cast<hipStream_t>(stream)));
+    return 0;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    double acc = 0.;
+    for (int b = 0; b < nplanes; ++b) acc += planes[(size_t)b * n + i];
+    out[i] = acc;
+  }
+  return 0;
+}
+}  // namespace
+
+int ecckd_rte_lw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                        const double *tau, const double *lay_source, const double *lev_source_inc,
+                        const double *lev_source_dec, const double *sfc_source, int nband, const int *band2gpt,
+                        const double *sfc_emis, double *bnd_flux_up, double *bnd_flux_dn, double *flux_up,
+                        double *flux_dn, int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  unsigned char map[256];
+  if (fill_band_map(ngpt, nband, band2gpt, map)) return 1;
+  if (!bnd_flux_up || !bnd_flux_dn) return fail("ecckd_rte_lw_byband: null argument");
+  const size_t n3 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1);
+  for (int b = 0; b < nband; ++b) {   // one solver pass per band over its (contiguous) g-points
+    const int g0 = band2gpt[2 * b] - 1, n = band2gpt[2 * b + 1] - g0;
+    const int one_band[2] = {1, n};
+    BandScope scope(b);
+    if (ecckd_rte_lw(device, ncol, nlay, n, top_at_1, n_gauss_angles, tau + n3 * g0, lay_source + n3 * g0,
+                     lev_source_inc + n3 * g0, lev_source_dec + n3 * g0, sfc_source + (size_t)ncol * g0, nband,
+                     one_band, sfc_emis, bnd_flux_up + n2l * b, bnd_flux_dn + n2l * b, memspace, stream))
+      return 1;
+  }
+  if (ncol == 0) return 0;
+  if (flux_up && sum_planes(bnd_flux_up, nband, n2l, flux_up, memspace, stream)) return 1;
+  if (flux_dn && sum_planes(bnd_flux_dn, nband, n2l, flux_dn, memspace, stream)) return 1;
+  return 0;
+}
+
+int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
+                        const double *ssa, const double *g, const double *mu0, const double *toa_flux, int nband,
+                        const int *band2gpt, const double *sfc_alb_dir, const double *sfc_alb_dif,
+                        double *bnd_flux_up, double *bnd_flux_dn, double *bnd_flux_dir, double *flux_up,
+                        double *flux_dn, double *flux_dir, int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  unsigned char map[256];
+  if (fill_band_map(ngpt, nband, band2gpt, map)) return 1;
+  if (!bnd_flux_up || !bnd_flux_dn) return fail("ecckd_rte_sw_byband: null argument");
+  if (flux_dir && !bnd_flux_dir) return fail("ecckd_rte_sw_byband: flux_dir needs bnd_flux_dir");
+  const size_t n3 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1);
+  for (int b = 0; b < nband; ++b) {
+    const int g0 = band2gpt[2 * b] - 1, n = band2gpt[2 * b + 1] - g0;
+    const int one_band[2] = {1, n};
+    BandScope scope(b);
+    if (ecckd_rte_sw(device, ncol, nlay, n, top_at_1, tau + n3 * g0, ssa + n3 * g0, g + n3 * g0, mu0,
+                     toa_flux + (size_t)ncol * g0, nband, one_band, sfc_alb_dir, sfc_alb_dif, bnd_flux_up + n2l * b,
+                     bnd_flux_dn + n2l * b, bnd_flux_dir ? bnd_flux_dir + n2l * b : nullptr, memspace, stream))
+      return 1;
+  }
+  if (ncol == 0) return 0;
+  if (flux_up && sum_planes(bnd_flux_up, nband, n2l, flux_up, memspace, stream)) return 1;
+  if (flux_dn && sum_planes(bnd_flux_dn, nband, n2l, flux_dn, memspace, stream)) return 1;
+  if (flux_dir && sum_planes(bnd_flux_dir, nband, n2l, flux_dir, memspace, stream)) return 1;
   return 0;
 }
 

@@ -131,6 +131,8 @@ int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);
+// out(i) = sum_b planes(i, b): broadband from per-band fluxes
+hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double *out, int f32, hipStream_t s);
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s);
 

@@ -247,6 +247,15 @@ __global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *to
     toa[q] = solar[q / ncol];   // src/gas_optics_ecckd.f90:468-472
 }
 
+template <typename real>
+__global__ void sum_planes_kernel(const real *planes, int nplanes, size_t n, real *out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    real acc = 0;
+    for (int b = 0; b < nplanes; ++b) acc += planes[(size_t)b * n + i];
+    out[i] = acc;
+  }
+}
+
 }  // namespace
 
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
@@ -277,6 +286,18 @@ hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(toa_src_kernel, dim3((unsigned)blocks), dim3(256), 0, s, solar, ncol, ng, toa_src);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double *out, int f32, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (f32)
+    hipLaunchKernelGGL(sum_planes_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(planes), nplanes, n, reinterpret_cast<float *>(out));
+  else
+    hipLaunchKernelGGL(sum_planes_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, planes, nplanes, n, out);
   return hipGetLastError();
 }
 

@@ -317,6 +317,65 @@ def test_gas_optics_marks_its_level_sources_as_shared(pkg, gpu, lw):
     assert torch.equal(fl[0].flux_up, fl[1].flux_up) and torch.equal(fl[0].flux_dn, fl[1].flux_dn)
 
 
+def test_fluxes_byband_lw_and_sw(pkg, gpu, oracle_mod):
+    """ty_fluxes_byband (RTE-RRTMGP callers; the reference drivers use the broadband type): per-band fluxes
+    equal the oracle run on each band's g-points alone, their sum equals the broadband call."""
+    import torch
+    rng = np.random.default_rng(77)
+    ng, nlay, ncol = 11, 60, 150
+    b2g = np.array([[1, 2], [3, 3], [4, 8], [9, 11]], dtype=np.int32)
+    nband = b2g.shape[0]
+    g2b = np.concatenate([[b] * (hi - lo + 1) for b, (lo, hi) in enumerate(b2g)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=gpu)
+    # ---- longwave ----
+    tau = rng.uniform(0, 2, (ng, nlay, ncol))
+    lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (ng, ncol))
+    emis = rng.uniform(0.7, 1.0, (ncol, nband))
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = b2g
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    bb = pkg.FluxesBroadband(z(nlay + 1, ncol), z(nlay + 1, ncol))
+    assert pkg.rte_lw(op, True, src, t(emis), bb, n_gauss_angles=2) == ""
+    fb = pkg.FluxesByband(z(nband, nlay + 1, ncol), z(nband, nlay + 1, ncol), flux_up=z(nlay + 1, ncol), flux_dn=z(nlay + 1, ncol))
+    assert pkg.rte_lw(op, True, src, t(emis), fb, n_gauss_angles=2) == ""
+    for b, (lo, hi) in enumerate(b2g):
+        sl = slice(lo - 1, hi)
+        fu, fd = oracle_mod.rte_lw(tau[sl], lay[sl], inc[sl], dec[sl], np.repeat(emis[None, :, b], hi - lo + 1, 0), sfc[sl], nmus=2)
+        assert np.max(np.abs(fb.bnd_flux_up[b].cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fb.bnd_flux_dn[b].cpu().numpy() - fd)) < FLUX_ATOL
+    assert torch.equal(fb.flux_up, fb.bnd_flux_up.sum(0)) or torch.allclose(fb.flux_up, fb.bnd_flux_up.sum(0), rtol=0, atol=1e-10)
+    assert torch.allclose(fb.flux_up, bb.flux_up, rtol=0, atol=FLUX_ATOL) and torch.allclose(fb.flux_dn, bb.flux_dn, rtol=0, atol=FLUX_ATOL)
+    # host arrays take the same route
+    hb = pkg.FluxesByband(np.zeros((nband, nlay + 1, ncol)), np.zeros((nband, nlay + 1, ncol)), flux_up=np.zeros((nlay + 1, ncol)))
+    oph = pkg.OpticalProps1scl(); oph.tau = tau; oph.band2gpt = b2g
+    sh = pkg.SourceFuncLW(); sh.lay_source, sh.lev_source_inc, sh.lev_source_dec, sh.sfc_source = lay, inc, dec, sfc
+    assert pkg.rte_lw(oph, True, sh, emis, hb, n_gauss_angles=2) == ""
+    assert np.array_equal(hb.bnd_flux_up, fb.bnd_flux_up.cpu().numpy()) and np.allclose(hb.flux_up, fb.flux_up.cpu().numpy(), rtol=0, atol=1e-10)
+    # ---- shortwave ----
+    ssa = rng.uniform(0, 1, (ng, nlay, ncol)); gg = rng.uniform(-0.3, 0.8, (ng, nlay, ncol))
+    mu0 = rng.uniform(0.1, 1.0, ncol); toa = rng.uniform(1, 50, (ng, ncol))
+    adir = rng.uniform(0.05, 0.4, (ncol, nband)); adif = rng.uniform(0.05, 0.4, (ncol, nband))
+    op2 = pkg.OpticalProps2str(); op2.tau, op2.ssa, op2.g, op2.band2gpt = t(tau), t(ssa), t(gg), b2g
+    sb = pkg.FluxesBroadband(z(nlay + 1, ncol), z(nlay + 1, ncol), z(nlay + 1, ncol))
+    assert pkg.rte_sw(op2, True, t(mu0), t(toa), t(adir), t(adif), sb) == ""
+    fs = pkg.FluxesByband(z(nband, nlay + 1, ncol), z(nband, nlay + 1, ncol), z(nband, nlay + 1, ncol),
+                          flux_up=z(nlay + 1, ncol), flux_dn=z(nlay + 1, ncol), flux_dn_dir=z(nlay + 1, ncol))
+    assert pkg.rte_sw(op2, True, t(mu0), t(toa), t(adir), t(adif), fs) == ""
+    for b, (lo, hi) in enumerate(b2g):
+        sl = slice(lo - 1, hi)
+        n = hi - lo + 1
+        fu, fd, fdir = oracle_mod.rte_sw(tau[sl], ssa[sl], gg[sl], mu0, toa[sl], np.repeat(adir[None, :, b], n, 0),
+                                         np.repeat(adif[None, :, b], n, 0))
+        assert np.max(np.abs(fs.bnd_flux_up[b].cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fs.bnd_flux_dn[b].cpu().numpy() - fd)) < FLUX_ATOL
+        assert np.max(np.abs(fs.bnd_flux_dn_dir[b].cpu().numpy() - fdir)) < FLUX_ATOL
+    for got, want in ((fs.flux_up, sb.flux_up), (fs.flux_dn, sb.flux_dn), (fs.flux_dn_dir, sb.flux_dn_dir)):
+        assert torch.allclose(got, want, rtol=0, atol=FLUX_ATOL)
+    assert g2b.shape[0] == ng
+
+
 def test_lw_36g_16band_model(pkg, gpu, oracle_mod):
     """The higher-g-point LW file present in the reference (rrtmgp-tol0.061: 36 g, 16 bands)."""
     import torch
