@@ -457,6 +457,30 @@ def test_sw_gas_optics_and_rte_sw(pkg, gpu, oracle_mod):
     assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)) < FLUX_ATOL
 
 
+def test_sw_gas_optics_orography(pkg, gpu, oracle_mod):
+    """Shortwave gas optics over columns whose surface pressure spans more pressure rows than the LDS slab
+    holds (slab positions, masked stores of tau / ssa / g)."""
+    import torch
+    k = pkg.GasOpticsEcckd()
+    assert k.load(SW_WIDE, device=0) == ""
+    m = oracle_mod.CkdModel(SW_WIDE)
+    ncol, nlay, ng = 1500, 60, 27
+    cols = orography_ramp(k.get_press_min(), ncol, c0=3)
+    cols["plev"][:, ::7] *= 0.8                      # every 7th column elsewhere: waves split between positions
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    names = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
+    gc = helpers.product_gas_concs(pkg, cols, t, names)
+    op = pkg.OpticalProps2str(); op.alloc_2str(ncol, nlay, k, like=t(np.zeros(1)))
+    toa = torch.empty((ng, ncol), dtype=torch.float64, device=gpu)
+    assert k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), gc, op, toa) == ""
+    otau, ossa, og, otoa, oerr = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"],
+                                                           helpers.oracle_gas_items(cols, names))
+    assert oerr == ""
+    assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
+    assert helpers.max_rel(op.ssa.cpu().numpy(), ossa) < TAU_RTOL
+    assert np.all(op.g.cpu().numpy() == 0)
+
+
 def test_modes_agree_to_a_few_ulp(pkg, gpu, lw):
     """fast vs reference-order arithmetic: same formula, re-associated."""
     k, _ = lw
