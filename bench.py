@@ -87,6 +87,9 @@ def main():
                     help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f64 = headline; f32 = single-precision flavour of the LW path (BASELINE configs[4] sweep)")
+    ap.add_argument("--arithmetic", choices=["fast", "reference"], default="fast",
+                    help="gas-optics arithmetic mode (ecckd_set_arithmetic): fast = fused kernel (headline); reference = "
+                         "per-gas kernels in the reference's expression order")
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     args = ap.parse_args()
@@ -116,6 +119,7 @@ def main():
 
     lw_file = LW_FILE if args.lut == "fsck" else LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061")
     L = pkg.lib()
+    pkg.set_arithmetic(pkg.FAST if args.arithmetic == "fast" else pkg.REFERENCE_ORDER)
     k = pkg.GasOpticsEcckd()
     err = k.load(lw_file, device=local_rank)
     if err:
