@@ -285,6 +285,44 @@ def main():
                 "pipeline_value": cells_per_gpu / ((ms_gas + ms_sh) * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s",
                 "fluxes_bit_identical_to_generic_solver": identical,
                 "note": "opt-in entry point; the headline value uses the generic ecckd_rte_lw, which reads both level arrays"}
+        # BASELINE configs[1] (the same workload at 1e5 columns) beside the 1e6-column headline
+        out["configs_1"] = None
+        if world == 1 and ncol > 100000 and args.lut == "fsck":
+            n1 = 100000
+            c1 = synthetic.columns(0, n1, press_min)
+            t1 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(tdt)
+            gc1 = pkg.GasConcs(synthetic.GAS_ORDER)
+            for name in synthetic.GAS_ORDER:
+                v = c1[name]
+                if np.isscalar(v):
+                    gc1.set_vmr(name, float(v))
+                elif v.ndim == 1:
+                    gc1.set_vmr_column(name, t1(v))
+                else:
+                    gc1.set_vmr(name, t1(v))
+            p1, ty1, tv1, ts1 = t1(c1["plev"]), t1(c1["tlay"]), t1(c1["tlev"]), t1(c1["tsfc"])
+            e1 = t1(np.repeat(c1["sfc_emis"][:, None], k.get_nband(), 1))
+            op1 = pkg.OpticalProps1scl(); op1.alloc_1scl(n1, nlay, k, like=p1)
+            src1 = pkg.SourceFuncLW(); src1.alloc(n1, nlay, k, like=p1)
+            fl1 = pkg.FluxesBroadband(torch.empty((nlay + 1, n1), **f64), torch.empty((nlay + 1, n1), **f64))
+
+            def step1():
+                e = k.gas_optics(None, p1, ty1, ts1, gc1, op1, src1, tlev=tv1) or pkg.rte_lw(op1, True, src1, e1, fl1, n_gauss_angles=1)
+                if e:
+                    raise SystemExit(e)
+
+            for _ in range(max(args.warmup, 1)):
+                step1()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t0) / args.steps
+            out["configs_1"] = {"workload": "synthetic 100000 columns x %d layers x %d g-points (BASELINE configs[1])" % (nlay, ng),
+                                "value": n1 * nlay * ng / dt1 / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": dt1 * 1e3,
+                                "frac_of_hbm_roofline": (total_b / ncol) * n1 / dt1 / 1e9 / HBM_PEAK_GBS}
+            del op1, src1, fl1
         out["host_memspace"] = None
         if args.host_sample > 0 and world == 1 and args.dtype == "f64":
             # The reference's calling convention: host arrays in and out (ECCKD_HOST).  Every call stages its
