@@ -260,27 +260,43 @@ static const double gauss_wts[4][4] = {{0.5, 0., 0., 0.},
 
 /* One quadrature angle for one g-point: lw_solver_noscat = transmittance, lw_source_noscat,
  * lw_transport_noscat, intensity -> flux.  radn_* are (ncol,nlay+1). */
+/* Version-sensitive details of the un-pinned RTE-RRTMGP solvers, as
+ * switches; the defaults are the v1.5-era forms the rest of this file restates. */
+void oracle_default_solver_options(oracle_solver_options_t *o) {
+  o->lw_tau_thresh = sqrt(2.220446049250313e-16); /* sqrt(epsilon(tau)) */
+  o->lw_series_terms = 2;
+  o->lw_inc_flux_isotropic = 0;
+  o->sw_k_floor = 1.e-12;
+  o->sw_dir_clamp = 0;
+}
+
 static void lw_solver_noscat(int ncol, int nlay, int top_at_1, double D, double weight,
                              const double *tau, const double *lay_source,
                              const double *lev_source_inc, const double *lev_source_dec,
-                             const double *sfc_emis, const double *sfc_src, double *radn_up,
+                             const double *sfc_emis, const double *sfc_src, const double *inc_flux,
+                             const oracle_solver_options_t *opt, double *radn_up,
                              double *radn_dn, double *tau_loc, double *trans, double *source_dn,
                              double *source_up) {
   const double pi = acos(-1.);
-  const double tau_thresh = sqrt(2.220446049250313e-16); /* sqrt(epsilon(tau)) */
+  const double tau_thresh = opt->lw_tau_thresh;
   const double *lev_source_up = top_at_1 ? lev_source_dec : lev_source_inc;
   const double *lev_source_dn = top_at_1 ? lev_source_inc : lev_source_dec;
   const int top_level = top_at_1 ? 0 : nlay;
-  /* no incident flux: radn_dn(top) = 0/(2 pi w) */
-  for (int i = 0; i < ncol; ++i) radn_dn[i + (long)ncol * top_level] = 0.;
+  /* flux at the top of the domain -> intensity assuming azimuthal isotropy (Appendix B.1:
+   * I_dn(top) = inc_flux/(2 pi w_k); no incident flux: 0).  lw_inc_flux_isotropic: inc_flux/pi for every
+   * angle, which makes flux_dn(top) == inc_flux with any number of angles. */
+  for (int i = 0; i < ncol; ++i)
+    radn_dn[i + (long)ncol * top_level] =
+        inc_flux ? (opt->lw_inc_flux_isotropic ? inc_flux[i] / pi : inc_flux[i] / (2. * pi * weight)) : 0.;
   for (int l = 0; l < nlay; ++l)
     for (int i = 0; i < ncol; ++i) {
       const long q = i + (long)ncol * l;
       tau_loc[q] = tau[q] * D;
       trans[q] = exp(-tau_loc[q]);
-      const double fact = (tau_loc[q] > tau_thresh)
-                              ? (1. - trans[q]) / tau_loc[q] - trans[q]
-                              : tau_loc[q] * (0.5 - 1. / 3. * tau_loc[q]);
+      const double tl = tau_loc[q];
+      const double series = opt->lw_series_terms >= 3 ? tl * (0.5 + tl * (-1. / 3. + tl * (1. / 8.)))
+                                                      : tl * (0.5 - 1. / 3. * tl);
+      const double fact = (tl > tau_thresh) ? (1. - trans[q]) / tl - trans[q] : series;
       source_dn[q] = (1. - trans[q]) * lev_source_dn[q] +
                      2. * fact * (lay_source[q] - lev_source_dn[q]);
       source_up[q] = (1. - trans[q]) * lev_source_up[q] +
@@ -328,6 +344,19 @@ void oracle_rte_lw(int ncol, int nlay, int ng, int top_at_1, int nmus, const dou
                    const double *lay_source, const double *lev_source_inc,
                    const double *lev_source_dec, const double *sfc_emis_gpt,
                    const double *sfc_source, double *flux_up, double *flux_dn) {
+  oracle_solver_options_t opt;
+  oracle_default_solver_options(&opt);
+  oracle_rte_lw_opt(ncol, nlay, ng, top_at_1, nmus, tau, lay_source, lev_source_inc, lev_source_dec, sfc_emis_gpt,
+                    sfc_source, NULL, &opt, flux_up, flux_dn);
+}
+
+/* rte_lw with the optional incident diffuse flux inc_flux(ncol,ng) at the top of the domain (NULL: none)
+ * and the version switches. */
+void oracle_rte_lw_opt(int ncol, int nlay, int ng, int top_at_1, int nmus, const double *tau,
+                       const double *lay_source, const double *lev_source_inc,
+                       const double *lev_source_dec, const double *sfc_emis_gpt,
+                       const double *sfc_source, const double *inc_flux,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn) {
   const long n2 = (long)ncol * nlay, n2l = (long)ncol * (nlay + 1);
   double *gup = (double *)malloc(sizeof(double) * n2l), *gdn = (double *)malloc(sizeof(double) * n2l);
   double *rup = (double *)malloc(sizeof(double) * n2l), *rdn = (double *)malloc(sizeof(double) * n2l);
@@ -336,12 +365,13 @@ void oracle_rte_lw(int ncol, int nlay, int ng, int top_at_1, int nmus, const dou
     const long o3 = n2 * k, o2 = (long)ncol * k;
     lw_solver_noscat(ncol, nlay, top_at_1, gauss_Ds[nmus - 1][0], gauss_wts[nmus - 1][0], tau + o3,
                      lay_source + o3, lev_source_inc + o3, lev_source_dec + o3, sfc_emis_gpt + o2,
-                     sfc_source + o2, gup, gdn, w1, w1 + n2, w1 + 2 * n2, w1 + 3 * n2);
+                     sfc_source + o2, inc_flux ? inc_flux + o2 : NULL, opt, gup, gdn, w1, w1 + n2, w1 + 2 * n2,
+                     w1 + 3 * n2);
     for (int imu = 1; imu < nmus; ++imu) { /* lw_solver_noscat_GaussQuad */
       lw_solver_noscat(ncol, nlay, top_at_1, gauss_Ds[nmus - 1][imu], gauss_wts[nmus - 1][imu],
                        tau + o3, lay_source + o3, lev_source_inc + o3, lev_source_dec + o3,
-                       sfc_emis_gpt + o2, sfc_source + o2, rup, rdn, w1, w1 + n2, w1 + 2 * n2,
-                       w1 + 3 * n2);
+                       sfc_emis_gpt + o2, sfc_source + o2, inc_flux ? inc_flux + o2 : NULL, opt, rup, rdn, w1,
+                       w1 + n2, w1 + 2 * n2, w1 + 3 * n2);
       for (long q = 0; q < n2l; ++q) { gup[q] = gup[q] + rup[q]; gdn[q] = gdn[q] + rdn[q]; }
     }
     /* sum_broadband: first g assigns, the rest accumulate in g order */
@@ -356,6 +386,17 @@ void oracle_rte_sw(int ncol, int nlay, int ng, int top_at_1, const double *tau,
                    const double *ssa, const double *g, const double *mu0, const double *toa,
                    const double *sfc_alb_dir_gpt, const double *sfc_alb_dif_gpt,
                    double *flux_up, double *flux_dn, double *flux_dir) {
+  oracle_solver_options_t opt;
+  oracle_default_solver_options(&opt);
+  oracle_rte_sw_opt(ncol, nlay, ng, top_at_1, tau, ssa, g, mu0, toa, sfc_alb_dir_gpt, sfc_alb_dif_gpt, &opt,
+                    flux_up, flux_dn, flux_dir);
+}
+
+void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *tau,
+                       const double *ssa, const double *g, const double *mu0, const double *toa,
+                       const double *sfc_alb_dir_gpt, const double *sfc_alb_dif_gpt,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
+                       double *flux_dir) {
   const double eps = 2.220446049250313e-16;
   const long n2l = (long)ncol * (nlay + 1);
   double *Rdif = (double *)malloc(sizeof(double) * nlay * 9 + sizeof(double) * (nlay + 1) * 6);
@@ -377,7 +418,7 @@ void oracle_rte_sw(int ncol, int nlay, int ng, int top_at_1, const double *tau,
         const double gamma4 = 1. - gamma3;
         const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
         const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-        const double kk = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.e-12));
+        const double kk = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), opt->sw_k_floor));
         const double exp_minusktau = exp(-t * kk);
         const double exp_minus2ktau = exp_minusktau * exp_minusktau;
         double RT_term = 1. / (kk * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
@@ -393,6 +434,10 @@ void oracle_rte_sw(int ncol, int nlay, int ng, int top_at_1, const double *tau,
         Tdir[l] = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * Tnoscat[l] -
                               (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * Tnoscat[l] -
                               2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+        if (opt->sw_dir_clamp) { /* later RTE releases: the direct beam can neither gain energy nor go negative */
+          Rdir[l] = dmax(0., dmin(Rdir[l], 1. - Tnoscat[l]));
+          Tdir[l] = dmax(0., dmin(Tdir[l], 1. - Tnoscat[l] - Rdir[l]));
+        }
       }
       /* sw_source_2str + adding, in "layer index from the top" coordinates */
       const int top = top_at_1 ? 0 : nlay;

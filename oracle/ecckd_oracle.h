@@ -101,6 +101,32 @@ void oracle_rte_lw(int ncol, int nlay, int ng, int top_at_1, int nmus, const dou
                    const double *lay_source, const double *lev_source_inc,
                    const double *lev_source_dec, const double *sfc_emis_gpt,
                    const double *sfc_source, double *flux_up, double *flux_dn);
+/* Version-sensitive details of the (un-pinned) solvers as switches; defaults = the v1.5-era forms:
+ *   lw_tau_thresh          optical depth below which lw_source_noscat uses the series (sqrt(epsilon))
+ *   lw_series_terms        2: tau*(0.5 - tau/3); 3: tau*(0.5 + tau*(-1/3 + tau/8)) (later releases)
+ *   lw_inc_flux_isotropic  0: I_dn(top) = inc_flux/(2 pi w_k) per angle; 1: inc_flux/pi
+ *   sw_k_floor             lower bound of (gamma1-gamma2)(gamma1+gamma2) under the square root (1e-12)
+ *   sw_dir_clamp           1: Rdir = max(0,min(Rdir,1-Tnoscat)), Tdir = max(0,min(Tdir,1-Tnoscat-Rdir)) (v1.6+) */
+typedef struct {
+  double lw_tau_thresh;
+  int lw_series_terms;
+  int lw_inc_flux_isotropic;
+  double sw_k_floor;
+  int sw_dir_clamp;
+} oracle_solver_options_t;
+void oracle_default_solver_options(oracle_solver_options_t *o);
+/* oracle_rte_lw + incident diffuse flux inc_flux(ncol,ng) at the top (NULL: none) + switches */
+void oracle_rte_lw_opt(int ncol, int nlay, int ng, int top_at_1, int nmus, const double *tau,
+                       const double *lay_source, const double *lev_source_inc,
+                       const double *lev_source_dec, const double *sfc_emis_gpt,
+                       const double *sfc_source, const double *inc_flux,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn);
+void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *tau,
+                       const double *ssa, const double *g, const double *mu0, const double *toa,
+                       const double *sfc_alb_dir_gpt, const double *sfc_alb_dif_gpt,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
+                       double *flux_dir);
+
 /* RTE-RRTMGP rte_sw, two-stream + adding; albedos are (ncol,ng). flux_dn includes direct. */
 void oracle_rte_sw(int ncol, int nlay, int ng, int top_at_1, const double *tau,
                    const double *ssa, const double *g, const double *mu0, const double *toa,

@@ -247,25 +247,46 @@ def gas_optics_ext(model, plev, tlay, gases, two_stream=True):
     return tau, ssa, g, toa, err.value.decode()
 
 
+class _SolverOptions(C.Structure):
+    _fields_ = [("lw_tau_thresh", C.c_double), ("lw_series_terms", C.c_int), ("lw_inc_flux_isotropic", C.c_int),
+                ("sw_k_floor", C.c_double), ("sw_dir_clamp", C.c_int)]
+
+
+def solver_options(**kw):
+    """oracle_solver_options_t with the v1.5-era defaults, overridden by keyword (lw_tau_thresh,
+    lw_series_terms, lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp)."""
+    o = _SolverOptions()
+    lib().oracle_default_solver_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
 def rte_lw(tau, lay_source, lev_source_inc, lev_source_dec, sfc_emis_gpt, sfc_source,
-           top_at_1=True, nmus=1):
+           top_at_1=True, nmus=1, inc_flux=None, options=None):
+    """inc_flux: (ng, ncol) incident diffuse flux at the top of the domain, or None."""
     ng, nlay, ncol = tau.shape
     fu = np.empty((nlay + 1, ncol))
     fd = np.empty_like(fu)
-    lib().oracle_rte_lw(ncol, nlay, ng, int(top_at_1), nmus, _p(_f64(tau)), _p(_f64(lay_source)),
-                        _p(_f64(lev_source_inc)), _p(_f64(lev_source_dec)), _p(_f64(sfc_emis_gpt)),
-                        _p(_f64(sfc_source)), _p(fu), _p(fd))
+    opt = options if options is not None else solver_options()
+    inc = None if inc_flux is None else _f64(inc_flux)
+    lib().oracle_rte_lw_opt(ncol, nlay, ng, int(top_at_1), nmus, _p(_f64(tau)), _p(_f64(lay_source)),
+                            _p(_f64(lev_source_inc)), _p(_f64(lev_source_dec)), _p(_f64(sfc_emis_gpt)),
+                            _p(_f64(sfc_source)), _p(inc), C.byref(opt), _p(fu), _p(fd))
     return fu, fd
 
 
-def rte_sw(tau, ssa, g, mu0, toa, alb_dir_gpt, alb_dif_gpt, top_at_1=True):
+def rte_sw(tau, ssa, g, mu0, toa, alb_dir_gpt, alb_dif_gpt, top_at_1=True, options=None):
     ngp, nlay, ncol = tau.shape
     fu = np.empty((nlay + 1, ncol))
     fd = np.empty_like(fu)
     fdir = np.empty_like(fu)
-    lib().oracle_rte_sw(ncol, nlay, ngp, int(top_at_1), _p(_f64(tau)), _p(_f64(ssa)), _p(_f64(g)),
-                        _p(_f64(mu0)), _p(_f64(toa)), _p(_f64(alb_dir_gpt)), _p(_f64(alb_dif_gpt)),
-                        _p(fu), _p(fd), _p(fdir))
+    opt = options if options is not None else solver_options()
+    lib().oracle_rte_sw_opt(ncol, nlay, ngp, int(top_at_1), _p(_f64(tau)), _p(_f64(ssa)), _p(_f64(g)),
+                            _p(_f64(mu0)), _p(_f64(toa)), _p(_f64(alb_dir_gpt)), _p(_f64(alb_dif_gpt)),
+                            C.byref(opt), _p(fu), _p(fd), _p(fdir))
     return fu, fd, fdir
 
 

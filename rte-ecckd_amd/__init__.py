@@ -50,7 +50,24 @@ def build(force=False, verbose=False):
         if all(os.path.getmtime(d) <= t for d in deps):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + srcs
+    # one object per source (in parallel, recompiled only when the source or a header is newer), then the link
+    objdir = os.path.join(_HERE, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(_CSRC, h)) for h in _HEADERS)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -265,11 +282,17 @@ class GasConcs:
     def get_gas_names(self):
         return list(self._names)
 
-    def entries(self, ncol, nlay):
+    def entries(self, ncol, nlay, known=None):
         """[(name, array-or-None, col_stride, lay_stride, scalar)] in gas order; raises KeyError
-        with the ty_gas_concs%get_vmr message for a gas that was never set."""
+        with the ty_gas_concs%get_vmr message for a gas that was never set.  `known`: gas names of the
+        k-distribution -- like the reference (src/gas_optics_ecckd.f90:348-364), get_vmr is only
+        consulted for gases the model holds a table for; the others cross the boundary as a name with
+        a null pointer (nothing is staged for them, and an unset one is not an error)."""
         out = []
         for n in self._names:
+            if known is not None and n not in known:
+                out.append((n, None, 0, 0, 0.0))
+                continue
             if n not in self._conc:
                 raise KeyError("ty_gas_concs%get_vmr; gas " + n + " not found")
             w = self._conc[n]
@@ -502,7 +525,7 @@ class GasOpticsEcckd:
 
     # -- gas_optics ---------------------------------------------------------------------
     def _gas_args(self, gas_desc, ncol, nlay, space, f32=False):
-        ent = gas_desc.entries(ncol, nlay)
+        ent = gas_desc.entries(ncol, nlay, known=set(self.get_gases()))
         n = len(ent)
         names = b"".join(e[0].encode().ljust(NAME_LEN, b" ") for e in ent)
         keep = []

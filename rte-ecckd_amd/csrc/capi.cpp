@@ -465,6 +465,10 @@ int ecckd_model_add_gas(ecckd_model_t *m, const char *name, int code, int compos
 int ecckd_model_finalize(ecckd_model_t *m, int device) {
   if (!m) return fail("ecckd_model_finalize: null model");
   if (m->finalized) return fail("ecckd_model_finalize: already finalized");
+  {
+    const std::string bad = ecckd::validate_model(*m);
+    if (!bad.empty()) return fail("ecckd_model_finalize: " + bad);
+  }
   if (device == -1) {   // host-only model: getters work, every compute call fails
     m->device = -1;
     m->finalized = true;

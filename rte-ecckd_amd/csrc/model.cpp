@@ -90,10 +90,12 @@ void load_and_init(ecckd_model &m, const std::string &filename) {
   // :55-78 bands
   std::vector<double> w1 = f.read("wavenumber1_band"), w2 = f.read("wavenumber2_band");
   m.nband = (int)w1.size();
+  if (m.nband < 1 || w2.size() != w1.size()) throw std::runtime_error("load_and_init_ecckd: no bands (wavenumber1_band / wavenumber2_band) in " + filename);
   m.band_lims_wvn.resize(2 * (size_t)m.nband);
   for (int b = 0; b < m.nband; ++b) { m.band_lims_wvn[2 * b] = w1[b]; m.band_lims_wvn[2 * b + 1] = w2[b]; }
   std::vector<double> bn = f.read("band_number");
   const int ngb = (int)bn.size();
+  if (ngb < 1) throw std::runtime_error("load_and_init_ecckd: empty band_number in " + filename);
   m.band2gpt.assign(2 * (size_t)m.nband, 0);
   m.band2gpt[0] = 1;
   m.band2gpt[2 * (m.nband - 1) + 1] = ngb;
@@ -159,6 +161,57 @@ void load_and_init(ecckd_model &m, const std::string &filename) {
     }
   }
   if (m.gas.size() > ECCKD_MAX_GASES) throw std::runtime_error("load_and_init_ecckd: more than 16 gases");
+  const std::string bad = validate_model(m);
+  if (!bad.empty()) throw std::runtime_error("load_and_init_ecckd: " + bad + " (" + filename + ")");
+}
+
+// Everything the kernels index without a bounds check, checked once: a short or inconsistent table is
+// an error at load time, never an out-of-bounds read on the device.  (The reference trusts the file:
+// mo_load_coefficients.F90 allocates from the file's own extents and would fail inside netcdf or with
+// a Fortran bounds error.)
+std::string validate_model(const ecckd_model &m) {
+  auto finite = [](const std::vector<double> &v) {
+    for (double x : v)
+      if (!(x - x == 0.)) return false;
+    return true;
+  };
+  if (m.ng < 1) return "no g-points (gpoint_fraction)";
+  if (m.ng > 256) return "more than 256 g-points";
+  if (m.np < 2) return "pressure grid needs at least 2 points";
+  if (m.nt < 2) return "temperature grid needs at least 2 points";
+  if (m.log_pressure.size() != (size_t)m.np) return "pressure has the wrong size";
+  if (m.temperature.size() != (size_t)m.np * m.nt) return "temperature is not (pressure, temperature)-shaped";
+  if (!finite(m.log_pressure) || !finite(m.temperature)) return "pressure/temperature grid is not finite (pressure must be > 0)";
+  if (!(m.log_pressure[1] - m.log_pressure[0] > 0.)) return "pressure grid must increase";
+  if (!(m.temperature[m.np] - m.temperature[0] > 0.)) return "temperature grid must increase";
+  if (m.nband < 1) return "no bands";
+  if (m.band2gpt.size() != 2 * (size_t)m.nband || m.band_lims_wvn.size() != 2 * (size_t)m.nband) return "band tables have the wrong size";
+  int next = 1;
+  for (int b = 0; b < m.nband; ++b) {   // contiguous, ascending cover of 1..ng
+    if (m.band2gpt[2 * b] != next || m.band2gpt[2 * b + 1] < m.band2gpt[2 * b]) return "band_number does not map the g-points onto contiguous bands";
+    next = m.band2gpt[2 * b + 1] + 1;
+  }
+  if (next != m.ng + 1) return "band_number does not cover every g-point (its length must equal the g-point count)";
+  if (m.has_planck) {
+    if (m.ntp < 2 || m.temperature_planck.size() != (size_t)m.ntp) return "temperature_planck needs at least 2 points";
+    if (m.planck_function.size() != (size_t)m.ng * m.ntp) return "planck_function is not (temperature_planck, g-point)-shaped";
+    if (!finite(m.temperature_planck) || !(m.temperature_planck[1] - m.temperature_planck[0] > 0.)) return "temperature_planck must increase";
+  }
+  if (m.has_solar) {
+    if (m.solar_irradiance.size() != (size_t)m.ng) return "solar_irradiance has the wrong size";
+    if (m.rayleigh.size() != (size_t)m.ng) return "rayleigh_molar_scattering_coeff has the wrong size";
+  }
+  for (const ecckd_model::Gas &g : m.gas) {
+    if (g.code < 0 || g.code > 3) return "bad concentration code for " + g.name;
+    if (g.nv < 1 || g.coef.size() != (size_t)m.ng * m.np * m.nt * g.nv) return "unexpected table size for " + g.name;
+    if (g.code == ECCKD_LOOK_UP_TABLE) {
+      if (g.nv < 2 || g.mole_fraction.size() != (size_t)g.nv) return "look-up-table gas " + g.name + " needs at least 2 mole fractions";
+      for (int k = 0; k < g.nv; ++k)
+        if (!(g.mole_fraction[k] > 0.) || (k > 0 && !(g.mole_fraction[k] > g.mole_fraction[k - 1])))
+          return "mole fractions of " + g.name + " must be positive and increasing";
+    }
+  }
+  return "";
 }
 
 }  // namespace ecckd

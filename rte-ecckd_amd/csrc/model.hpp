@@ -46,6 +46,8 @@ struct ecckd_model {
 namespace ecckd {
 // load_and_init (example/rfmip-rad-irf/mo_load_coefficients.F90:19-146); throws on error.
 void load_and_init(ecckd_model &m, const std::string &filename);
+// "" if every table has the extents the kernels assume, else what is wrong (load and builder routes)
+std::string validate_model(const ecckd_model &m);
 // mo_load_coefficients.F90:244-293 (including the dropped single-character last token)
 std::vector<std::string> tokenize(const std::string &buffer);
 }  // namespace ecckd

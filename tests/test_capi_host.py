@@ -85,6 +85,65 @@ def test_cdf2_and_small_model_roundtrip(pkg, oracle_mod, tmp_path):
     assert oracle_mod.CkdModel(p).gas == ["x", "y"]
 
 
+def _write_tiny(path, np_=4, nt=3, ng=2, ntp=5, nband=1, ngb=None, planck_g=None, t_shape=None, mf=(1e-6, 1e-5),
+                band_number=None, p_values=None):
+    """A tiny ecCKD-style file with knobs for every extent the kernels index (test_malformed_tables...)."""
+    from scipy.io import netcdf_file
+    ngb = ng if ngb is None else ngb
+    planck_g = ng if planck_g is None else planck_g
+    f = netcdf_file(path, "w")
+    dims = dict(temperature=nt, pressure=np_, g_point=ng, temperature_planck=ntp, wavenumber=3, x_mole_fraction=len(mf),
+                gb=ngb, pg=planck_g)
+    if nband > 0:
+        dims["band"] = nband
+    for n, d in dims.items():
+        f.createDimension(n, d)
+    if t_shape is not None:
+        f.createDimension("tt", t_shape[0]); f.createDimension("tp", t_shape[1])
+    v = f.createVariable("pressure", "f4", ("pressure",))
+    v[:] = p_values if p_values is not None else 10.0 ** (1 + np.arange(np_))
+    tdims = ("tt", "tp") if t_shape is not None else ("temperature", "pressure")
+    v = f.createVariable("temperature", "f4", tdims)
+    shp = t_shape if t_shape is not None else (nt, np_)
+    v[:] = 200 + 20 * np.arange(shp[0])[:, None] + np.arange(shp[1])[None, :]
+    v = f.createVariable("temperature_planck", "f4", ("temperature_planck",)); v[:] = 100 + 50 * np.arange(ntp)
+    v = f.createVariable("planck_function", "f4", ("temperature_planck", "pg")); v[:] = 1.0
+    v = f.createVariable("gpoint_fraction", "f4", ("g_point", "wavenumber")); v[:] = 0.5
+    if nband > 0:
+        v = f.createVariable("wavenumber1_band", "f4", ("band",)); v[:] = np.arange(nband) * 100.
+        v = f.createVariable("wavenumber2_band", "f4", ("band",)); v[:] = (np.arange(nband) + 1) * 100.
+    v = f.createVariable("band_number", "i2", ("gb",)); v[:] = band_number if band_number is not None else np.zeros(ngb)
+    v = f.createVariable("x_mole_fraction", "f4", ("x_mole_fraction",)); v[:] = mf
+    v = f.createVariable("x_molar_absorption_coeff", "f4", ("x_mole_fraction", "temperature", "pressure", "g_point")); v[:] = 1.0
+    f.constituent_id = "x z"     # (the single-character last token is dropped, as in the reference)
+    f.close()
+
+
+def test_malformed_tables_are_load_errors(pkg, tmp_path):
+    """Extents the kernels index without a bounds check are validated at load / finalize time:
+    a short or inconsistent table is an error message, never an out-of-bounds read on the host or the device."""
+    k = pkg.GasOpticsEcckd()
+    p = str(tmp_path / "m.nc")
+    _write_tiny(p)
+    assert k.load(p, device=-1) == ""                      # the well-formed form of the same file loads
+    cases = [(dict(np_=1), "pressure grid"), (dict(nt=1), "temperature grid"), (dict(ntp=1), "temperature_planck"),
+             (dict(planck_g=1), "planck_function"), (dict(ngb=1), "band_number"), (dict(ngb=3), "band_number"),
+             (dict(t_shape=(3, 5)), "temperature"), (dict(mf=(1e-5, 1e-6)), "mole fractions"),
+             (dict(mf=(0.0, 1e-6)), "mole fractions"), (dict(nband=2, band_number=[0, 0]), "band"),
+             (dict(band_number=[0, 5]), "band"), (dict(p_values=[10., 100., -1., 1e4]), "pressure")]
+    for knobs, word in cases:
+        _write_tiny(p, **knobs)
+        err = k.load(p, device=-1)
+        assert err != "" and word in err, (knobs, err)
+    # the builder route goes through the same checks at finalize
+    lp = np.log([10., 100., 1000.]); T = 200. + np.arange(6).reshape(2, 3)
+    coef = np.ones((2, 3, 2))
+    bad = k.init_from_tables(lp, T, [dict(name="x", code=1, coefficient=coef)], planck=(np.array([100., 90.]), np.ones((2, 2))), device=-1)
+    assert "temperature_planck" in bad
+    ok = k.init_from_tables(lp, T, [dict(name="x", code=1, coefficient=coef)], planck=(np.array([100., 200.]), np.ones((2, 2))), device=-1)
+    assert ok == ""
+
+
 def test_no_gpu_means_error_not_fallback(pkg):
     """On a machine without a GPU every compute entry point must fail loudly."""
     import torch

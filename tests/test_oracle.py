@@ -173,3 +173,82 @@ def test_rte_sw_beer_lambert_and_conservation(oracle_mod):
     ones = np.ones_like(tau)
     fu, fd, fdir = oracle_mod.rte_sw(tau, ones, zeros, mu0, toa, np.zeros((ng, ncol)), np.zeros((ng, ncol)))
     assert np.allclose(fd[0] - fu[0], fd[-1] - fu[-1], rtol=1e-5)
+
+
+# ---------------- node-identity known answers from the reference-held LUT files ----------------
+@pytest.mark.parametrize("path", [LW_FSCK, LW_RRTMGP])
+def test_planck_sources_on_table_nodes(oracle_mod, path):
+    """T == temperature_planck(k)  =>  sources == planck_function(:,k)/pi_f32, bit for bit."""
+    import helpers
+    m = oracle_mod.CkdModel(path)
+    cols, want = helpers.planck_node_case(m)
+    tau, lay, inc, dec, sfc, err = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"], [], cols["tlev"])
+    assert err == ""
+    assert np.array_equal(sfc, want)
+    for a in (lay, inc, dec):
+        assert np.array_equal(a, np.repeat(want[:, None, :], 3, 1))
+
+
+@pytest.mark.parametrize("path", [LW_FSCK, SW_WIDE])
+def test_tau_on_table_nodes(oracle_mod, path):
+    """p, T (and the h2o mole fraction) on table nodes => tau == weight * coefficient(:,ip,it), bit for bit."""
+    import helpers
+    m = oracle_mod.CkdModel(path)
+    for name, cols, item, want in helpers.tau_node_cases(m):
+        if m.shortwave:
+            tau = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"], [item], two_stream=False)[0]
+            ray = helpers.GLOBAL_WEIGHT * (cols["plev"][1] - cols["plev"][0])[None, None, :] * m.rayleigh[:, None, None]
+            assert np.array_equal(tau, want + ray), name      # :456 tau = gas + Rayleigh
+        else:
+            tau = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"], [item], cols["tlev"])[0]
+            assert np.array_equal(tau, want), name
+        assert np.all(want >= 0) and np.any(want > 0)
+
+
+# ---------------- solver switches and the incident-flux boundary condition ----------------
+def test_rte_lw_incident_flux(oracle_mod):
+    """Transparent column: F_dn = sum_g inc_flux at every level; an absorbing one
+    attenuates it by exp(-D tau)."""
+    rng = np.random.default_rng(11)
+    ng, nlay, ncol = 4, 6, 5
+    z = np.zeros((ng, nlay, ncol))
+    inc = rng.uniform(1, 9, (ng, ncol))
+    emis = np.ones((ng, ncol))
+    fu, fd = oracle_mod.rte_lw(z, z, z, z, emis, np.zeros((ng, ncol)), inc_flux=inc)
+    assert np.allclose(fd, inc.sum(0)[None, :], rtol=1e-15) and np.all(fu == 0)
+    fu0, fd0 = oracle_mod.rte_lw(z, z, z, z, emis, np.zeros((ng, ncol)))
+    assert np.all(fd0 == 0)
+    tau = rng.uniform(0.1, 1.0, (ng, nlay, ncol))
+    _, fd = oracle_mod.rte_lw(tau, z, z, z, emis, np.zeros((ng, ncol)), inc_flux=inc)
+    want = (inc[:, None, :] * np.exp(-1.66 * np.cumsum(tau, 1))).sum(0)
+    assert np.allclose(fd[1:], want, rtol=1e-13)
+    # bottom-up orientation gives the mirrored answer
+    f = lambda a: np.ascontiguousarray(a[:, ::-1, :])
+    _, fd2 = oracle_mod.rte_lw(f(tau), z, z, z, emis, np.zeros((ng, ncol)), inc_flux=inc, top_at_1=False)
+    assert np.array_equal(fd2[::-1], fd)
+    # n angles: the literal B.1 form feeds every angle the full flux; the isotropic switch conserves it
+    _, fd3 = oracle_mod.rte_lw(z, z, z, z, emis, np.zeros((ng, ncol)), inc_flux=inc, nmus=3)
+    assert np.allclose(fd3, 3 * inc.sum(0)[None, :], rtol=1e-14)
+    iso = oracle_mod.solver_options(lw_inc_flux_isotropic=1)
+    _, fd4 = oracle_mod.rte_lw(z, z, z, z, emis, np.zeros((ng, ncol)), inc_flux=inc, nmus=3, options=iso)
+    assert np.allclose(fd4, inc.sum(0)[None, :], rtol=1e-9)
+
+
+def test_solver_switches(oracle_mod):
+    rng = np.random.default_rng(12)
+    ng, nlay, ncol = 3, 5, 40
+    # LW: the series branch only matters below the threshold; a 3-term series moves tiny-tau layers by O(tau^4)
+    tau = rng.uniform(0, 1e-3, (ng, nlay, ncol))
+    B = rng.uniform(1, 9, (ng, nlay, ncol)); B2 = rng.uniform(1, 9, (ng, nlay, ncol))
+    sfc = rng.uniform(1, 9, (ng, ncol)); emis = np.full((ng, ncol), 0.95)
+    base = oracle_mod.rte_lw(tau, B, B2, B2, emis, sfc)
+    hi = oracle_mod.rte_lw(tau, B, B2, B2, emis, sfc, options=oracle_mod.solver_options(lw_tau_thresh=1e-2, lw_series_terms=3))
+    assert not np.array_equal(hi[1], base[1]) and np.allclose(hi[1], base[1], rtol=0, atol=1e-8)
+    # SW: mu0 close to 1/k makes Rdir/Tdir ill-conditioned; the clamps keep 0 <= Rdir <= 1 - Tnoscat
+    tau = rng.uniform(0.01, 3.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.999999, (ng, nlay, ncol)); g = rng.uniform(0, 0.9, (ng, nlay, ncol))
+    mu0 = rng.uniform(0.05, 1.0, ncol); toa = rng.uniform(10, 100, (ng, ncol)); alb = np.full((ng, ncol), 0.2)
+    a = oracle_mod.rte_sw(tau, ssa, g, mu0, toa, alb, alb)
+    b = oracle_mod.rte_sw(tau, ssa, g, mu0, toa, alb, alb, options=oracle_mod.solver_options(sw_dir_clamp=1))
+    assert np.allclose(a[0], b[0], rtol=0, atol=5.0) and np.array_equal(a[2], b[2])   # the direct beam is untouched
+    c = oracle_mod.rte_sw(tau, ssa, g, mu0, toa, alb, alb, options=oracle_mod.solver_options(sw_k_floor=1e-3))
+    assert np.allclose(a[0], c[0], rtol=1e-2)
