@@ -41,35 +41,154 @@ def algorithmic_bytes_per_column(ng, nlay=NLAY):
     return {"tau": tau, "planck": planck, "rte_lw": rte, "gas_lw_fused": tau + planck}
 
 
+def columns_per_gpu(gpus, ncol_arg):
+    """Columns per GPU when --ncol is not given: 1e6 (the north_star target size, weak scaling) for 1, 2, 4 GPUs;
+    with 8 GPUs the job is BASELINE configs[3]: 1e7 columns, column-range sharded 1.25e6 per rank."""
+    if ncol_arg is not None:
+        return int(ncol_arg)
+    return 1250000 if gpus == 8 else 1000000
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the kernel sources: ties a committed PMC traffic file to the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rte-ecckd_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".hip") or f == "kernels.hpp":
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(name, key):
+    """HBM bytes per launch of kernel `key` from the committed rocprofv3 PMC passes profiles/<name> -- only if
+    that file was measured on THIS build of the kernels (kernel_sha), else None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if tj.get("kernel_sha") != kernel_source_sha():
+            return None, "profiles/%s was measured on another build of the kernels (kernel_sha differs): not quoted" % name
+        return tj["kernels"][key]["hbm_bytes_per_launch"], ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                                            "passes of this workload and build, gfx950-corrected)" % name)
+    except Exception as e:   # no file, no such kernel
+        return None, "no committed PMC pass for this workload (%s)" % type(e).__name__
+
+
 def cpu_baseline(args, press_min):
-    """The CPU restatement (oracle/, 'port' of the reference Fortran: same per-gas passes and
-    temporaries as src/gas_optics_ecckd.f90:117-240,370 plus the RTE LW recurrences) timed on this
-    host's cores over a bounded sample of the same synthetic columns, column blocks spread over
-    OpenMP threads."""
+    """The CPU restatement (oracle/, 'port' of the reference Fortran: same per-gas passes and temporaries as
+    src/gas_optics_ecckd.f90:117-240,370 plus the RTE LW recurrences) timed on this host's cores over bounded
+    samples of the same synthetic columns.  Legs:
+      value          all host cores, column blocks of --cpu-block spread over OpenMP threads
+      one_thread     1 thread, block = 1 (what the reference driver does: ecckd_rfmip_lw.F90:39) and block = 1000"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from rte_ecckd_amd import synthetic
     m = oracle.CkdModel(LW_FILE)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def timed(n, block, nthreads):
+        cols = synthetic.columns(0, n, press_min)
+        items = synthetic.gas_items(cols)
+        t0 = time.perf_counter()
+        oracle.lw_pipeline(m, cols["plev"], cols["tlay"], cols["tlev"], cols["tsfc"], items, cols["sfc_emis"],
+                           block=block, nthreads=nthreads)
+        return max(time.perf_counter() - t0, 1e-6)
+
+    def leg(block, nthreads, seconds, probe_n):
+        dt = timed(probe_n, block, nthreads)
+        n = int(min(args.ncol or 1000000, max(probe_n, probe_n * seconds / dt)))
+        n -= n % (block * nthreads) or 0
+        n = max(n, block * nthreads)
+        dt = timed(n, block, nthreads)
+        return n, dt, n * NLAY * m.ng / dt / 1e6
+
     block = args.cpu_block
-    probe_n = 64 * cores
-    cols = synthetic.columns(0, probe_n, press_min)
-    t0 = time.perf_counter()
-    oracle.lw_pipeline(m, cols["plev"], cols["tlay"], cols["tlev"], cols["tsfc"], synthetic.gas_items(cols),
-                       cols["sfc_emis"], block=block, nthreads=cores)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(args.ncol, max(probe_n, probe_n * args.cpu_seconds / dt)))
-    n -= n % (block * cores) or 0
-    n = max(n, block * cores)
-    cols = synthetic.columns(0, n, press_min)
-    items = synthetic.gas_items(cols)
-    t0 = time.perf_counter()
-    oracle.lw_pipeline(m, cols["plev"], cols["tlay"], cols["tlev"], cols["tsfc"], items, cols["sfc_emis"],
-                       block=block, nthreads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n * NLAY * m.ng / dt / 1e6, "unit": "Mcol*lay*gpt/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic columns x %d layers x %d g-points, column blocks of %d over %d OpenMP "
-                      "threads, %.1f s" % (n, NLAY, m.ng, block, cores, dt)}
+    n, dt, rate = leg(block, cores, args.cpu_seconds, 64 * cores)
+    out = {"value": rate, "unit": "Mcol*lay*gpt/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "nproc": os.cpu_count(),
+           "sample": "%d synthetic columns x %d layers x %d g-points, column blocks of %d over %d OpenMP "
+                     "threads, %.1f s" % (n, NLAY, m.ng, block, cores, dt)}
+    legs = {}
+    for blk in (1, 1000):
+        n1, dt1, r1 = leg(blk, 1, args.cpu_seconds / 3.0, max(blk, 8))
+        legs["block_%d" % blk] = {"value": r1, "unit": "Mcol*lay*gpt/s", "cores": 1,
+                                  "sample": "%d columns, blocks of %d, 1 thread, %.1f s" % (n1, blk, dt1)}
+    out["one_thread"] = legs
+    return out
+
+
+class LwCase:
+    """Device-resident inputs, intermediates and outputs of one LW gas_optics + rte_lw workload (columns
+    c0 .. c0+ncol-1 of the counter-based synthetic generator) and the step that runs it."""
+
+    def __init__(self, pkg, k, ncol, c0, dev, tdt, press_min):
+        import torch
+        from rte_ecckd_amd import synthetic
+        self.pkg, self.k, self.ncol = pkg, k, ncol
+        nlay = NLAY
+        kw = dict(dtype=tdt, device=dev)
+        self.plev = torch.empty((nlay + 1, ncol), **kw)
+        self.tlev = torch.empty((nlay + 1, ncol), **kw)
+        self.tlay = torch.empty((nlay, ncol), **kw)
+        h2o = torch.empty((nlay, ncol), **kw)
+        o3 = torch.empty((nlay, ncol), **kw)
+        self.percol = {n: torch.empty((ncol,), **kw) for n in ("tsfc", "sfc_emis", "co2", "ch4", "n2o", "cfc11", "cfc12")}
+        chunk = 100000
+        for s0 in range(0, ncol, chunk):      # generated in chunks on the host
+            n = min(chunk, ncol - s0)
+            cols = synthetic.columns(c0 + s0, n, press_min)
+            for dst, key in ((self.plev, "plev"), (self.tlev, "tlev"), (self.tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
+                dst[:, s0:s0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
+            for key, dst in self.percol.items():
+                dst[s0:s0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
+        self.gc = pkg.GasConcs(synthetic.GAS_ORDER)
+        for name in synthetic.GAS_ORDER:
+            if name in ("h2o", "o3"):
+                self.gc.set_vmr(name, h2o if name == "h2o" else o3)
+            elif name in self.percol:
+                self.gc.set_vmr_column(name, self.percol[name])
+            else:
+                self.gc.set_vmr(name, 0.209 if name == "o2" else 0.0)
+        self.emis = self.percol["sfc_emis"].reshape(ncol, 1).expand(ncol, k.get_nband()).contiguous()
+        self.op = pkg.OpticalProps1scl()
+        self.op.alloc_1scl(ncol, nlay, k, like=self.plev)
+        self.src = pkg.SourceFuncLW()
+        self.src.alloc(ncol, nlay, k, like=self.plev)
+        self.fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), **kw), torch.empty((nlay + 1, ncol), **kw))
+
+    def step(self, shared_levels=False):
+        e = self.k.gas_optics(None, self.plev, self.tlay, self.percol["tsfc"], self.gc, self.op, self.src, tlev=self.tlev)
+        e = e or self.pkg.rte_lw(self.op, True, self.src, self.emis, self.fl, n_gauss_angles=1, shared_levels=shared_levels)
+        if e:
+            raise SystemExit(e)
+
+    def timed(self, steps, warmup):
+        import torch
+        for _ in range(max(warmup, 1)):
+            self.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+
+def prof_report(L):
+    names = C.create_string_buffer(8 * 32)
+    ms = (C.c_double * 8)()
+    cnt = (C.c_longlong * 8)()
+    nk = L.ecckd_prof_report(8, names, ms, cnt)
+    return {names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): (ms[i] / max(cnt[i], 1), int(cnt[i])) for i in range(nk)}
 
 
 def main():
@@ -77,12 +196,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ncol", type=int, default=1000000, help="synthetic columns per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--ncol", type=int, default=None,
+                    help="synthetic columns per GPU (default: 1e6, the north_star target size; with --gpus 8: 1.25e6 = "
+                         "BASELINE configs[3], 1e7 columns sharded over 8 GPUs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget of the all-cores leg (0 = skip)")
     ap.add_argument("--host-sample", type=int, default=20000,
                     help="columns of the PCIe-inclusive side measurement through the ECCKD_HOST memory space "
                          "(host arrays in, host arrays out; 0 = skip).  Reported beside the headline, never as it.")
-    ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the CPU baseline")
+    ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the all-cores CPU baseline leg")
     ap.add_argument("--lut", choices=["fsck", "rrtmgp"], default="fsck",
                     help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
@@ -92,8 +213,11 @@ def main():
                          "per-gas kernels in the reference's expression order")
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
+    ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling passes)")
     args = ap.parse_args()
     if args.mode == "sw":
+        if args.ncol is None:
+            args.ncol = 100000
         return main_sw(args)
 
     import torch
@@ -124,49 +248,17 @@ def main():
     err = k.load(lw_file, device=local_rank)
     if err:
         raise SystemExit(err)
-    ng, ncol, nlay = k.get_ngpt(), args.ncol, NLAY
+    ncol = columns_per_gpu(world, args.ncol)
+    args.ncol = ncol
+    ng, nlay = k.get_ngpt(), NLAY
     press_min = k.get_press_min()
-
-    # ---- synthetic inputs, generated in chunks on the host, resident on the device ----
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     f64 = dict(dtype=tdt, device=dev)
-    plev = torch.empty((nlay + 1, ncol), **f64)
-    tlev = torch.empty((nlay + 1, ncol), **f64)
-    tlay = torch.empty((nlay, ncol), **f64)
-    h2o = torch.empty((nlay, ncol), **f64)
-    o3 = torch.empty((nlay, ncol), **f64)
-    percol = {n: torch.empty((ncol,), **f64) for n in ("tsfc", "sfc_emis", "co2", "ch4", "n2o", "cfc11", "cfc12")}
-    chunk = 100000
-    for c0 in range(0, ncol, chunk):
-        n = min(chunk, ncol - c0)
-        cols = synthetic.columns(rank * ncol + c0, n, press_min)
-        for dst, key in ((plev, "plev"), (tlev, "tlev"), (tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
-            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
-        for key, dst in percol.items():
-            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
-    gc = pkg.GasConcs(synthetic.GAS_ORDER)
-    for name in synthetic.GAS_ORDER:
-        if name in ("h2o", "o3"):
-            gc.set_vmr(name, h2o if name == "h2o" else o3)
-        elif name in percol:
-            gc.set_vmr_column(name, percol[name])
-        else:
-            gc.set_vmr(name, 0.209 if name == "o2" else 0.0)
-    emis = percol["sfc_emis"].reshape(ncol, 1).expand(ncol, k.get_nband()).contiguous()
 
-    op = pkg.OpticalProps1scl()
-    op.alloc_1scl(ncol, nlay, k, like=plev)
-    src = pkg.SourceFuncLW()
-    src.alloc(ncol, nlay, k, like=plev)
-    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), **f64), torch.empty((nlay + 1, ncol), **f64))
-
-    def step():
-        e = k.gas_optics(None, plev, tlay, percol["tsfc"], gc, op, src, tlev=tlev)
-        if e:
-            raise SystemExit(e)
-        e = pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1)
-        if e:
-            raise SystemExit(e)
+    # rank r holds columns [r*ncol, (r+1)*ncol) of the generator: column-range sharding, no data-path collective
+    case = LwCase(pkg, k, ncol, rank * ncol, dev, tdt, press_min)
+    fl, op, src, emis = case.fl, case.op, case.src, case.emis
+    step = case.step
 
     def barrier():
         if distributed:
@@ -182,23 +274,23 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0      # this rank's own time, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     L.ecckd_prof_enable(0)
 
     # per-kernel HIP-event durations recorded inside the timed region
-    names = C.create_string_buffer(8 * 32)
-    ms = (C.c_double * 8)()
-    cnt = (C.c_longlong * 8)()
-    nk = L.ecckd_prof_report(8, names, ms, cnt)
-    kern = {}
-    for i in range(nk):
-        kern[names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode()] = (ms[i] / max(cnt[i], 1), int(cnt[i]))
+    kern = prof_report(L)
 
+    rank_ms = [t_rank / args.steps * 1e3]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([t_rank / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [float(x.item()) for x in allr]
 
     if rank == 0:
         cells_per_gpu = ncol * nlay * ng
@@ -215,19 +307,13 @@ def main():
                                 "GBps": b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}
         dom = max(kern, key=lambda n: kern[n][0]) if kern else None
         roofline = None
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01h_hbm_traffic.json")))
-            if ncol == 1000000 and args.dtype == "f64" and args.lut == "fsck" and dom in tj["kernels"]:
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
         if dom:
+            traffic, tsrc = (None, "only quoted for the 1e6-column fp64 fsck workload")
+            if ncol == 1000000 and args.dtype == "f64" and args.lut == "fsck" and args.arithmetic == "fast":
+                traffic, tsrc = committed_traffic("r02_hbm_traffic.json", dom)
             ach = per_kernel[dom]["GBps"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": "profiles/r01h_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                          "gfx950-corrected)" if traffic else None,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "avg_launch_ms": per_kernel[dom]["avg_ms"],
                         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes_per_launch"]}
         total_b = (bpc["tau"] + bpc["planck"] + bpc["rte_lw"]) * ncol
@@ -242,16 +328,25 @@ def main():
         fu, fd = oracle.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None, :], ng, 0), sfc)
         dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].double().cpu().numpy() - fu))),
                     float(np.max(np.abs(fl.flux_dn[:, :64].double().cpu().numpy() - fd))))
+        if world == 8 and ncol == 1250000:
+            what = "BASELINE configs[3]: 1e7 synthetic columns, column-range sharded 1.25e6 per GPU over 8 GPUs"
+        elif ncol == 1000000:
+            what = "north_star target size, 1e6 columns per GPU (configs[1] is the same workload at 1e5 columns: key configs_1)"
+        elif ncol == 100000:
+            what = "BASELINE configs[1] size"
+        else:
+            what = "custom size"
         out = {
             "metric": "Mcol*lay*gpt/s LW gas_optics+rte_lw", "value": value, "unit": "Mcol*lay*gpt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": ("synthetic %d columns x %d layers x %d g-points per GPU, LW " % (ncol, nlay, ng)) + os.path.basename(lw_file)[36:-3] + ", "
-                                   "gas_optics + rte_lw (1 angle), " + ("fp64" if args.dtype == "f64" else "fp32") + ", inputs and intermediates HBM-resident; "
-                                   "north_star target size (configs[1] is the same workload at 1e5 columns)"
-                                   ,
-                       "ncol_per_gpu": ncol, "nlay": nlay, "ngpt": ng, "parallelism": "column-range x%d" % world},
+                                   "gas_optics + rte_lw (1 angle), " + ("fp64" if args.dtype == "f64" else "fp32") + ", inputs and intermediates HBM-resident; " + what,
+                       "ncol_per_gpu": ncol, "ncol_total": ncol * world, "nlay": nlay, "ngpt": ng,
+                       "parallelism": "column-range x%d, no collective" % world,
+                       "arithmetic": args.arithmetic, "solver_options": pkg.solver_options()},
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms},
             "roofline": roofline,
             "roofline_pipeline": {"bound": "hbm", "achieved": pipe, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": pipe / HBM_PEAK_GBS, "alg_bytes_per_cell": total_b / ncol / (nlay * ng),
@@ -259,6 +354,7 @@ def main():
             "kernels": per_kernel,
             "check_max_abs_flux_diff_vs_oracle_Wm2": dflux,
         }
+        side = world == 1 and not args.no_side
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, press_min)
         else:
@@ -266,7 +362,7 @@ def main():
         # Side measurement (not the headline): the solver told that ecckd's level sources hold one value per level
         # (ecckd_rte_lw_shared_levels): 24 instead of 32 B/cell read, bit-identical fluxes.
         out["rte_lw_shared_levels"] = None
-        if world == 1 and args.dtype == "f64":
+        if side and args.dtype == "f64":
             ref_up = fl.flux_up.clone()
             for _ in range(2):
                 e = pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1, shared_levels=True)
@@ -285,46 +381,25 @@ def main():
                 "pipeline_value": cells_per_gpu / ((ms_gas + ms_sh) * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s",
                 "fluxes_bit_identical_to_generic_solver": identical,
                 "note": "opt-in entry point; the headline value uses the generic ecckd_rte_lw, which reads both level arrays"}
-        # BASELINE configs[1] (the same workload at 1e5 columns) beside the 1e6-column headline
+        del case, fl, op, src, emis
+        torch.cuda.empty_cache()
+        # BASELINE configs[1] (the same workload at 1e5 columns) and one rank's shard of configs[3] (1e7 columns over
+        # 8 GPUs = 1.25e6 per rank; the LAST rank's columns) beside the 1e6-column headline
         out["configs_1"] = None
-        if world == 1 and ncol > 100000 and args.lut == "fsck":
-            n1 = 100000
-            c1 = synthetic.columns(0, n1, press_min)
-            t1 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(tdt)
-            gc1 = pkg.GasConcs(synthetic.GAS_ORDER)
-            for name in synthetic.GAS_ORDER:
-                v = c1[name]
-                if np.isscalar(v):
-                    gc1.set_vmr(name, float(v))
-                elif v.ndim == 1:
-                    gc1.set_vmr_column(name, t1(v))
-                else:
-                    gc1.set_vmr(name, t1(v))
-            p1, ty1, tv1, ts1 = t1(c1["plev"]), t1(c1["tlay"]), t1(c1["tlev"]), t1(c1["tsfc"])
-            e1 = t1(np.repeat(c1["sfc_emis"][:, None], k.get_nband(), 1))
-            op1 = pkg.OpticalProps1scl(); op1.alloc_1scl(n1, nlay, k, like=p1)
-            src1 = pkg.SourceFuncLW(); src1.alloc(n1, nlay, k, like=p1)
-            fl1 = pkg.FluxesBroadband(torch.empty((nlay + 1, n1), **f64), torch.empty((nlay + 1, n1), **f64))
-
-            def step1():
-                e = k.gas_optics(None, p1, ty1, ts1, gc1, op1, src1, tlev=tv1) or pkg.rte_lw(op1, True, src1, e1, fl1, n_gauss_angles=1)
-                if e:
-                    raise SystemExit(e)
-
-            for _ in range(max(args.warmup, 1)):
-                step1()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step1()
-            torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t0) / args.steps
-            out["configs_1"] = {"workload": "synthetic 100000 columns x %d layers x %d g-points (BASELINE configs[1])" % (nlay, ng),
-                                "value": n1 * nlay * ng / dt1 / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": dt1 * 1e3,
-                                "frac_of_hbm_roofline": (total_b / ncol) * n1 / dt1 / 1e9 / HBM_PEAK_GBS}
-            del op1, src1, fl1
+        out["configs_3_shard"] = None
+        if side and ncol == 1000000 and args.lut == "fsck":
+            for key, n1, c0, label in (("configs_1", 100000, 0, "synthetic 100000 columns x %d layers x %d g-points (BASELINE configs[1])"),
+                                       ("configs_3_shard", 1250000, 7 * 1250000,
+                                        "columns 8750000..9999999 of 1e7 x %d layers x %d g-points: the last rank's shard of BASELINE "
+                                        "configs[3] (1e7 columns over 8 GPUs), run on one GPU")):
+                c1 = LwCase(pkg, k, n1, c0, dev, tdt, press_min)
+                dt1 = c1.timed(args.steps, args.warmup)
+                out[key] = {"workload": label % (nlay, ng), "value": n1 * nlay * ng / dt1 / 1e6, "unit": "Mcol*lay*gpt/s",
+                            "ms_per_step": dt1 * 1e3, "frac_of_hbm_roofline": (total_b / ncol) * n1 / dt1 / 1e9 / HBM_PEAK_GBS}
+                del c1
+                torch.cuda.empty_cache()
         out["host_memspace"] = None
-        if args.host_sample > 0 and world == 1 and args.dtype == "f64":
+        if args.host_sample > 0 and side and args.dtype == "f64":
             # The reference's calling convention: host arrays in and out (ECCKD_HOST).  Every call stages its
             # arguments over PCIe, so this is the PCIe-inclusive rate of the same two calls.
             n = min(args.host_sample, ncol)

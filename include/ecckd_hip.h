@@ -16,6 +16,9 @@
  *     (pointers are device pointers on the model's GPU; the call is asynchronous on
  *     `stream`).  Small descriptor arrays (gas names, pointer tables, strides, Ds/weights,
  *     band2gpt) are always host memory.
+ *     ECCKD_DEVICE calls never synchronise and never allocate once a (shape, stream) pair has been
+ *     seen: they can be captured in a HIP graph after one warm-up call on the capturing stream (the
+ *     solvers' scratch rings are per stream, see ecckd_set_stream_scratch).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - Return value: 0 on success, non-zero on error; the message (same texts as the
  *     reference's character(len=128) results, src/gas_optics_ecckd.f90:331,393,442) is
@@ -28,6 +31,8 @@
  */
 #ifndef ECCKD_HIP_H
 #define ECCKD_HIP_H
+
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -188,6 +193,16 @@ int ecckd_rte_lw_shared_levels(int device, int ncol, int nlay, int ngpt, int top
                                const double *sfc_emis, double *flux_up, double *flux_dn,
                                int memspace, void *stream);
 
+/* ecckd_rte_lw with the optional incident diffuse flux at the top of the domain: rte_lw's `inc_flux(ncol,ngpt)`
+ * argument [RTE-RRTMGP; no reference call site passes it: ecckd_rfmip_lw.F90:130-135].  I_dn(top) =
+ * inc_flux/(2 pi w_k) for quadrature angle k (see the solver option
+ * lw_inc_flux_isotropic).  inc_flux == NULL is ecckd_rte_lw.  fp64, generic level sources. */
+int ecckd_rte_lw_inc_flux(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                          const double *tau, const double *lay_source, const double *lev_source_inc,
+                          const double *lev_source_dec, const double *sfc_source, int nband,
+                          const int *band2gpt, const double *sfc_emis, const double *inc_flux,
+                          double *flux_up, double *flux_dn, int memspace, void *stream);
+
 /* Single-precision flavour of ecckd_rte_lw. */
 int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
                      const float *tau, const float *lay_source, const float *lev_source_inc,
@@ -236,7 +251,7 @@ int ecckd_gas_optics_plan(const ecckd_model_t *model, int ncol, int nlay, int si
                           int ngas, const char *gas_names, int *plan);
 
 /* ---------------------------------------------------------------------------------------
- * Arithmetic mode of gas_optics (process-wide).
+ * Arithmetic mode of gas_optics (process-wide, atomic; read once per call).
  *   0 (default) fast: one fused kernel per call; the interpolation weights of a cell are
  *               multiplied out once and each coefficient costs one FMA.  Same formula as
  *               src/gas_optics_ecckd.f90:167-221, re-associated: tau differs from mode 1 by a
@@ -249,6 +264,37 @@ int ecckd_gas_optics_plan(const ecckd_model_t *model, int ncol, int nlay, int si
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_arithmetic(int mode);
 int ecckd_get_arithmetic(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Version switches of the solvers (process-wide; read once per call).  RTE-RRTMGP is an un-pinned dependency
+ * of the reference (.github/workflows/continuous-integration.yml:98-102 checks out its default branch), and a few
+ * details of rte_lw / rte_sw changed between releases.  The defaults are the v1.5-era forms; a host linked
+ * against a later RTE-RRTMGP selects the matching forms here.  bench.py prints the active values.
+ *   "lw_tau_thresh"          lw_source_noscat uses the series below this tau*D (default sqrt(epsilon(1._wp));
+ *                            later releases: sqrt(sqrt(epsilon)));  <= 0 restores the default
+ *   "lw_series_terms"        2: tau*(0.5 - tau/3) (default);  3: tau*(0.5 + tau*(-1/3 + tau/8))
+ *   "lw_inc_flux_isotropic"  0: I_dn(top) = inc_flux/(2 pi w_k) per angle (default);
+ *                            1: inc_flux/pi (flux_dn(top) == inc_flux with any number of angles)
+ *   "sw_k_floor"             k = sqrt(max((gamma1-gamma2)(gamma1+gamma2), sw_k_floor)), default 1e-12
+ *   "sw_dir_clamp"           1: Rdir = max(0,min(Rdir,1-Tnoscat)), Tdir = max(0,min(Tdir,1-Tnoscat-Rdir))
+ *                            (v1.6+); 0: no clamp (default)
+ * --------------------------------------------------------------------------------------- */
+int ecckd_set_solver_option(const char *name, double value);
+int ecckd_get_solver_option(const char *name, double *value);
+
+/* ---------------------------------------------------------------------------------------
+ * Solver scratch (no counterpart in the reference).  ecckd_rte_sw (always) and ecckd_rte_lw (more than 96
+ * layers) keep per-wave rings in global memory.  By default the library owns one block per (device, stream),
+ * allocated at the first call that needs it and reused by every later call on that stream without any
+ * synchronisation; inside a stream capture nothing is allocated (a call that would have to fails with a
+ * message).  ecckd_set_stream_scratch hands a caller-owned device buffer over for the calls on `stream`
+ * (buffer == NULL, bytes == 0 takes it back); ecckd_*_scratch_bytes say how much a shape needs (0: none);
+ * ecckd_release_scratch synchronises the device and frees every library-owned block.
+ * --------------------------------------------------------------------------------------- */
+size_t ecckd_rte_lw_scratch_bytes(int ncol, int nlay, int ngpt);
+size_t ecckd_rte_sw_scratch_bytes(int ncol, int nlay, int ngpt);
+int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t bytes);
+int ecckd_release_scratch(int device);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement hooks (no counterpart in the reference, which has no timers: SURVEY.md §5).

@@ -150,6 +150,13 @@ def lib():
     L.ecckd_model_add_gas.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_double, C.c_void_p]
     L.ecckd_gas_optics_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+    L.ecckd_set_solver_option.argtypes = [C.c_char_p, C.c_double]
+    L.ecckd_get_solver_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+    for f in ("ecckd_rte_lw_scratch_bytes", "ecckd_rte_sw_scratch_bytes"):
+        getattr(L, f).restype = C.c_size_t
+        getattr(L, f).argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ecckd_set_stream_scratch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ecckd_release_scratch.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -170,6 +177,59 @@ def set_arithmetic(mode):
 
 def get_arithmetic():
     return lib().ecckd_get_arithmetic()
+
+
+SOLVER_OPTIONS = ("lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor", "sw_dir_clamp")
+
+
+def set_solver_option(name, value):
+    """Version switches of rte_lw / rte_sw (ecckd_set_solver_option in include/ecckd_hip.h); the defaults
+    are the RTE-RRTMGP v1.5-era forms."""
+    if lib().ecckd_set_solver_option(name.encode(), float(value)):
+        raise ValueError(last_error())
+
+
+def get_solver_option(name):
+    v = C.c_double()
+    if lib().ecckd_get_solver_option(name.encode(), C.byref(v)):
+        raise ValueError(last_error())
+    return v.value
+
+
+def solver_options():
+    """The active switches as a dict (bench.py prints it)."""
+    return {n: get_solver_option(n) for n in SOLVER_OPTIONS}
+
+
+def reset_solver_options():
+    for n, v in (("lw_tau_thresh", 0.0), ("lw_series_terms", 2), ("lw_inc_flux_isotropic", 0), ("sw_k_floor", 1e-12),
+                 ("sw_dir_clamp", 0)):
+        set_solver_option(n, v)
+
+
+def rte_sw_scratch_bytes(ncol, nlay, ngpt):
+    return int(lib().ecckd_rte_sw_scratch_bytes(int(ncol), int(nlay), int(ngpt)))
+
+
+def rte_lw_scratch_bytes(ncol, nlay, ngpt):
+    return int(lib().ecckd_rte_lw_scratch_bytes(int(ncol), int(nlay), int(ngpt)))
+
+
+def set_stream_scratch(buffer, device=None, stream=None):
+    """Hand a caller-owned device buffer (a torch CUDA uint8/any tensor, or None to take it back) to the solver
+    calls on `stream` (default: torch's current stream) -- ecckd_set_stream_scratch."""
+    import torch
+    st = torch.cuda.current_stream() if stream is None else stream
+    dev = (buffer.device.index if buffer is not None else torch.cuda.current_device()) if device is None else device
+    ptr = C.c_void_p(buffer.data_ptr()) if buffer is not None else None
+    n = buffer.numel() * buffer.element_size() if buffer is not None else 0
+    if lib().ecckd_set_stream_scratch(int(dev or 0), C.c_void_p(st.cuda_stream), ptr, n):
+        raise ValueError(last_error())
+
+
+def release_scratch(device=0):
+    if lib().ecckd_release_scratch(int(device)):
+        raise RuntimeError(last_error())
 
 
 # ------------------------------------------------------------------------------------------
@@ -602,12 +662,13 @@ def _device_of(a):
 
 
 def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1, device=None,
-           shared_levels=False):
+           shared_levels=False, inc_flux=None):
     """``rte_lw(optical_props, top_at_1, sources, sfc_emis(nband,ncol), fluxes, n_gauss_angles=)``
     (ecckd_rfmip_lw.F90:130-135).  ``sfc_emis`` is ``(ncol, nband)`` in numpy order.  float32 arrays
     take the single-precision entry point.  ``shared_levels=True`` asserts that the level sources hold
     one value per level (``sources.levels_shared``, set by ecckd's gas_optics) and takes
-    ``ecckd_rte_lw_shared_levels`` (fp64 only)."""
+    ``ecckd_rte_lw_shared_levels`` (fp64 only).  ``inc_flux`` ``(ngpt, ncol)``: incident diffuse flux at the
+    top of the domain (rte_lw's optional argument; ``ecckd_rte_lw_inc_flux``, fp64, generic solver)."""
     ng, nlay, ncol = optical_props.tau.shape
     b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
     nband = b2g.shape[0]
@@ -631,6 +692,20 @@ def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1,
         return last_error() if rc else ""
     if shared_levels and f32:
         return "rte_lw: shared_levels is implemented for float64 arrays"
+    if inc_flux is not None:
+        if f32 or shared_levels:
+            return "rte_lw: inc_flux is implemented for float64 arrays and the generic solver"
+        space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, inc_flux, fluxes.flux_up, fluxes.flux_dn])
+        rc = lib().ecckd_rte_lw_inc_flux(
+            int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), _ptr(optical_props.tau),
+            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
+            _ptr(sfc_emis, (ncol, nband), "sfc_emis"), _ptr(inc_flux, (ng, ncol), "inc_flux"),
+            _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
+            space, _stream(space))
+        return last_error() if rc else ""
     fn = lib().ecckd_rte_lw_f32 if f32 else (lib().ecckd_rte_lw_shared_levels if shared_levels else lib().ecckd_rte_lw)
     P = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
     rc = fn(int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), P(optical_props.tau),

@@ -4,8 +4,10 @@
 // error returned to the caller.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -58,7 +60,47 @@ struct Arena {
   }
 };
 Arena g_solver_arena[16];
-Arena g_scratch_arena[16];   // generic-nlay solver scratch (device flavours too)
+
+// Scratch rings of the solvers (rte_sw always; rte_lw beyond 96 layers), stream-ordered: a launch takes the
+// block that belongs to (device, stream).  Work on one stream is ordered, so consecutive calls on a stream
+// reuse its block without any synchronisation, and calls on different streams never share one -- the call
+// stays asynchronous and can be captured in a HIP graph.  A block that has become too small is retired, not
+// freed (a kernel in flight or a captured graph may still hold its address) and a larger one is allocated;
+// retired blocks are released by ecckd_release_scratch() or when the process ends.  A caller that wants no
+// allocation inside the library at all hands its own buffer over with ecckd_set_stream_scratch().
+struct ScratchPool {
+  std::mutex mu;
+  struct Block { void *p = nullptr; size_t bytes = 0; bool caller_owned = false; };
+  std::map<hipStream_t, Block> live;
+  std::vector<void *> retired;
+};
+ScratchPool g_scratch_pool[16];
+
+// Returns the scratch block of (device, stream) with at least `need` bytes in *out.
+int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
+  ScratchPool &pool = g_scratch_pool[device];
+  std::lock_guard<std::mutex> lock(pool.mu);
+  ScratchPool::Block &b = pool.live[stream];
+  if (b.bytes >= need) { *out = b.p; return 0; }
+  if (b.caller_owned)
+    return fail("ecckd: the scratch buffer set with ecckd_set_stream_scratch is too small for this call (" +
+                std::to_string(need) + " bytes needed: ecckd_rte_lw_scratch_bytes / ecckd_rte_sw_scratch_bytes)");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail("ecckd: this call needs " + std::to_string(need) + " bytes of solver scratch on a stream that is being "
+                "captured; run the call once on this stream before the capture, or hand a buffer over with "
+                "ecckd_set_stream_scratch (no allocation happens inside a capture)");
+  void *p = nullptr;
+  size_t want = need + need / 4;   // head room: a slightly larger shape on the same stream does not reallocate
+  if (hipMalloc(&p, want) != hipSuccess) {
+    want = need;
+    HIPCHK(hipMalloc(&p, want));
+  }
+  if (b.p) pool.retired.push_back(b.p);
+  b.p = p; b.bytes = want; b.caller_owned = false;
+  *out = p;
+  return 0;
+}
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -67,6 +109,7 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // keep their `double *` static type on the way through (they are only passed on, never indexed).
 thread_local int g_f32 = 0;
 thread_local int g_shared_levels = 0;
+thread_local const double *g_inc_flux = nullptr;   // set by ecckd_rte_lw_inc_flux around ecckd_rte_lw
 // set by the *_byband entry points around the per-band solver calls: band of every g-point of the sub-range
 thread_local int g_band_override = -1;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
@@ -83,7 +126,18 @@ struct F32Scope {
 
 // Arithmetic mode (ecckd_set_arithmetic): 0 = fast (fused kernel, re-associated FMAs),
 // 1 = reference order (kernels_tau.hip + kernels_planck.hip, bit-faithful expression order).
-int g_arith = 0;
+std::atomic<int> g_arith{0};
+
+// Version switches of the (un-pinned) RTE-RRTMGP solvers, ecckd_set_solver_option.  Process-wide, read once
+// per call; the defaults are the v1.5-era forms the oracle restates.
+struct SolverOptions {
+  std::atomic<double> lw_tau_thresh{0.};        // <= 0: sqrt(epsilon) of the working precision
+  std::atomic<int> lw_series_terms{2};
+  std::atomic<int> lw_inc_flux_isotropic{0};
+  std::atomic<double> sw_k_floor{1.e-12};
+  std::atomic<int> sw_dir_clamp{0};
+};
+SolverOptions g_opt;
 
 // ---- optional per-kernel timing with HIP events on the launch stream (ecckd_prof_*) ----
 struct ProfRec { const char *name; hipEvent_t start, stop; };
@@ -181,7 +235,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
   // Split the sequence into passes holding at most one look_up_table gas and kTauPassGases
   // gases each; later passes start from the tau already stored, so the summation order of :370
   // is preserved exactly in the reference-order mode.
-  const bool fast = g_arith == 0;
+  const bool fast = g_arith.load() == 0;
   size_t pos = 0;
   bool first_pass = true;
   do {
@@ -190,6 +244,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.np = m->np; a.nt = m->nt;
     a.plev = plev; a.tlay = tlay;
     a.temperature = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_temperature) : m->dbuf + m->off_temperature;
+    a.zero = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_zero) : m->dbuf + m->off_zero;
     a.lp0 = m->log_pressure[0];                               // :104
     a.dlp = m->log_pressure[1] - m->log_pressure[0];          // :105
     a.dt = m->temperature[m->np] - m->temperature[0];         // :106 T(1,2)-T(1,1)
@@ -347,11 +402,74 @@ const char *ecckd_build_info(void) {
 
 int ecckd_set_arithmetic(int mode) {
   if (mode != 0 && mode != 1) return fail("ecckd_set_arithmetic: mode must be 0 (fast) or 1 (reference order)");
-  g_arith = mode;
+  g_arith.store(mode);
   return 0;
 }
 
-int ecckd_get_arithmetic(void) { return g_arith; }
+int ecckd_get_arithmetic(void) { return g_arith.load(); }
+
+int ecckd_set_solver_option(const char *name, double value) {
+  if (!name) return fail("ecckd_set_solver_option: null name");
+  const std::string n(name);
+  if (!(value - value == 0.)) return fail("ecckd_set_solver_option: value must be finite");
+  if (n == "lw_tau_thresh") g_opt.lw_tau_thresh.store(value);                       // <= 0 restores the default
+  else if (n == "lw_series_terms") {
+    if (value != 2. && value != 3.) return fail("ecckd_set_solver_option: lw_series_terms must be 2 or 3");
+    g_opt.lw_series_terms.store((int)value);
+  } else if (n == "lw_inc_flux_isotropic") g_opt.lw_inc_flux_isotropic.store(value != 0. ? 1 : 0);
+  else if (n == "sw_k_floor") {
+    if (!(value > 0.)) return fail("ecckd_set_solver_option: sw_k_floor must be > 0");
+    g_opt.sw_k_floor.store(value);
+  } else if (n == "sw_dir_clamp") g_opt.sw_dir_clamp.store(value != 0. ? 1 : 0);
+  else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp)");
+  return 0;
+}
+
+int ecckd_get_solver_option(const char *name, double *value) {
+  if (!name || !value) return fail("ecckd_get_solver_option: null argument");
+  const std::string n(name);
+  if (n == "lw_tau_thresh") { const double t = g_opt.lw_tau_thresh.load(); *value = t > 0. ? t : std::sqrt(2.220446049250313e-16); }
+  else if (n == "lw_series_terms") *value = g_opt.lw_series_terms.load();
+  else if (n == "lw_inc_flux_isotropic") *value = g_opt.lw_inc_flux_isotropic.load();
+  else if (n == "sw_k_floor") *value = g_opt.sw_k_floor.load();
+  else if (n == "sw_dir_clamp") *value = g_opt.sw_dir_clamp.load();
+  else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
+  return 0;
+}
+
+size_t ecckd_rte_lw_scratch_bytes(int ncol, int nlay, int ngpt) {
+  return ncol > 0 && nlay > 0 ? ecckd::rte_lw_scratch_bytes(ncol, nlay, ngpt) : 0;
+}
+size_t ecckd_rte_sw_scratch_bytes(int ncol, int nlay, int ngpt) {
+  return ncol > 0 && nlay > 0 ? ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt) : 0;
+}
+
+int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t bytes) {
+  if (device < 0 || device >= 16) return fail("ecckd_set_stream_scratch: bad device ordinal");
+  if ((buffer == nullptr) != (bytes == 0)) return fail("ecckd_set_stream_scratch: buffer and size must both be given, or neither");
+  ScratchPool &pool = g_scratch_pool[device];
+  std::lock_guard<std::mutex> lock(pool.mu);
+  ScratchPool::Block &b = pool.live[static_cast<hipStream_t>(stream)];
+  if (b.p && !b.caller_owned) pool.retired.push_back(b.p);
+  b.p = buffer; b.bytes = bytes; b.caller_owned = buffer != nullptr;
+  return 0;
+}
+
+int ecckd_release_scratch(int device) {
+  if (device < 0 || device >= 16) return fail("ecckd_release_scratch: bad device ordinal");
+  ScratchPool &pool = g_scratch_pool[device];
+  std::lock_guard<std::mutex> lock(pool.mu);
+  if (pool.live.empty() && pool.retired.empty()) return 0;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());   // nothing in flight may still use a block
+  for (auto &kv : pool.live)
+    if (kv.second.p && !kv.second.caller_owned) (void)hipFree(kv.second.p);
+  for (void *p : pool.retired) (void)hipFree(p);
+  pool.live.clear();
+  pool.retired.clear();
+  return 0;
+}
 
 int ecckd_prof_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof_mu);
@@ -487,6 +605,7 @@ int ecckd_model_finalize(ecckd_model_t *m, int device) {
     while (host.size() % 32) host.push_back(0.);
     return off;
   };
+  m->off_zero = put(std::vector<double>(32, 0.));
   m->off_temperature = put(m->temperature);
   if (m->has_planck) m->off_planck = put(m->planck_function);
   if (m->has_solar) { m->off_rayleigh = put(m->rayleigh); m->off_solar = put(m->solar_irradiance); }
@@ -816,47 +935,54 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   a.nband = nband;
   a.f32 = g_f32;
   a.shared_levels = g_shared_levels;
+  {
+    const double t = g_opt.lw_tau_thresh.load();
+    a.tau_thresh = t > 0. ? t : (g_f32 ? std::sqrt(1.1920928955078125e-07) : std::sqrt(2.220446049250313e-16));   // sqrt(epsilon(1._wp))
+    a.series3 = g_opt.lw_series_terms.load() == 3;
+    a.inc_isotropic = g_opt.lw_inc_flux_isotropic.load();
+  }
   for (int k = 0; k < n_gauss_angles; ++k) {
     a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
     a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
   }
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const size_t scratch = ecckd::rte_lw_scratch_bytes(ncol, nlay, ngpt);
-  Arena &sa = g_scratch_arena[device];
-  std::unique_lock<std::mutex> slock(sa.mu, std::defer_lock);
-  if (scratch) {
-    slock.lock();
-    if (sa.ensure(scratch)) return 1;
-    a.scratch = static_cast<double *>(sa.p);
+  const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
+  if (scratch) {   // more than 96 layers: stream-ordered scratch ring, no synchronisation (see ScratchPool)
+    void *sp = nullptr;
+    if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
+    a.scratch = static_cast<double *>(sp);
   }
   if (memspace == ECCKD_DEVICE) {
     a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc;
     a.lev_source_dec = lev_source_dec; a.sfc_source = sfc_source; a.sfc_emis = sfc_emis;
     a.flux_up = flux_up; a.flux_dn = flux_dn;
+    a.inc_flux = g_inc_flux;
     {
-      ProfScope prof("rte_lw", static_cast<hipStream_t>(stream));
-      HIPCHK(ecckd::launch_rte_lw(a, static_cast<hipStream_t>(stream)));
+      ProfScope prof("rte_lw", launch_stream);
+      HIPCHK(ecckd::launch_rte_lw(a, launch_stream));
     }
-    if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // scratch is shared
     return 0;
   }
   if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
   Arena &ar = g_solver_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
-  const size_t need = align256(n3 * esz()) * 4 + align256((size_t)ncol * ngpt * esz()) +
+  const size_t need = align256(n3 * esz()) * 4 + align256((size_t)ncol * ngpt * esz()) * 2 +
                       align256((size_t)ncol * nband * esz()) + align256(n2l * esz()) * 2;
   if (ar.ensure(need)) return 1;
   Bump b(ar.p);
   double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
   double *d_sfc = b.take((size_t)ncol * ngpt), *d_emis = b.take((size_t)ncol * nband);
-  double *d_up = b.take(n2l), *d_dn = b.take(n2l);
+  double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_incf = b.take((size_t)ncol * ngpt);
   hipStream_t s = nullptr;
   if (h2d(d_tau, tau, n3, s) || h2d(d_lay, lay_source, n3, s) || h2d(d_inc, lev_source_inc, n3, s) ||
       h2d(d_dec, lev_source_dec, n3, s) || h2d(d_sfc, sfc_source, (size_t)ncol * ngpt, s) ||
       h2d(d_emis, sfc_emis, (size_t)ncol * nband, s))
     return 1;
+  if (g_inc_flux && h2d(d_incf, g_inc_flux, (size_t)ncol * ngpt, s)) return 1;
   a.tau = d_tau; a.lay_source = d_lay; a.lev_source_inc = d_inc; a.lev_source_dec = d_dec;
   a.sfc_source = d_sfc; a.sfc_emis = d_emis; a.flux_up = d_up; a.flux_dn = d_dn;
+  a.inc_flux = g_inc_flux ? d_incf : nullptr;
   HIPCHK(ecckd::launch_rte_lw(a, s));
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
@@ -888,6 +1014,19 @@ int ecckd_rte_lw_shared_levels(int device, int ncol, int nlay, int ngpt, int top
                       lev_source_dec, sfc_source, nband, band2gpt, sfc_emis, flux_up, flux_dn, memspace, stream);
 }
 
+int ecckd_rte_lw_inc_flux(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                          const double *tau, const double *lay_source, const double *lev_source_inc,
+                          const double *lev_source_dec, const double *sfc_source, int nband,
+                          const int *band2gpt, const double *sfc_emis, const double *inc_flux, double *flux_up,
+                          double *flux_dn, int memspace, void *stream) {
+  struct Scope {
+    explicit Scope(const double *p) { g_inc_flux = p; }
+    ~Scope() { g_inc_flux = nullptr; }
+  } scope(inc_flux);
+  return ecckd_rte_lw(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, tau, lay_source, lev_source_inc,
+                      lev_source_dec, sfc_source, nband, band2gpt, sfc_emis, flux_up, flux_dn, memspace, stream);
+}
+
 int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
                  const double *ssa, const double *g, const double *mu0, const double *toa_flux,
                  int nband, const int *band2gpt, const double *sfc_alb_dir,
@@ -902,25 +1041,25 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (check_device(device)) return 1;
   if (ncol == 0) return 0;
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nband = nband;
-  a.exact_division = g_arith != 0;
+  a.exact_division = g_arith.load() != 0;
+  a.k_floor = g_opt.sw_k_floor.load();
+  a.dir_clamp = g_opt.sw_dir_clamp.load();
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
-  Arena &sa = g_scratch_arena[device];
-  std::unique_lock<std::mutex> slock(sa.mu, std::defer_lock);
-  if (scratch) {
-    slock.lock();
-    if (sa.ensure(scratch)) return 1;
-    a.scratch = static_cast<double *>(sa.p);
+  const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
+  if (scratch) {   // stream-ordered scratch ring, no synchronisation (see ScratchPool)
+    void *sp = nullptr;
+    if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
+    a.scratch = static_cast<double *>(sp);
   }
   if (memspace == ECCKD_DEVICE) {
     a.tau = tau; a.ssa = ssa; a.g = g; a.mu0 = mu0; a.toa = toa_flux;
     a.alb_dir = sfc_alb_dir; a.alb_dif = sfc_alb_dif;
     a.flux_up = flux_up; a.flux_dn = flux_dn; a.flux_dir = flux_dir;
     {
-      ProfScope prof("rte_sw", static_cast<hipStream_t>(stream));
-      HIPCHK(ecckd::launch_rte_sw(a, static_cast<hipStream_t>(stream)));
+      ProfScope prof("rte_sw", launch_stream);
+      HIPCHK(ecckd::launch_rte_sw(a, launch_stream));
     }
-    if (scratch) HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return 0;
   }
   if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");

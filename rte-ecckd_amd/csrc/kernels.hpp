@@ -31,6 +31,7 @@ struct TauArgs {
   int ncol, nlay, ng, np, nt;
   const double *plev, *tlay;
   const double *temperature;   // (np,nt) device; only T(:,1) is used (:131-132)
+  const double *zero;          // a zero word of the model's device image (loads of unused / scalar gas slots)
   double lp0, dlp, dt, gw;     // :104-107
   int nseq;
   SeqGas seq[kMaxSeq];
@@ -52,7 +53,8 @@ struct UDiv { double d, r; int exact; };
 
 // Per-slot view of the gases of a pass for the fused kernel: slot s < nbil is the s-th bilinear
 // gas, slot kTauPassGases is the look_up_table gas.  `vmr` is ALWAYS a valid device address (the
-// load is issued unconditionally, all slots in one round).  The mole fraction that enters the
+// load is issued unconditionally, all slots in one round; slots without an array read TauArgs::zero, a
+// word the model owns, so that a NaN in the caller's arrays stays in its own column).  The mole fraction that enters the
 // weight is fma(alpha, loaded, beta) with alpha in {0, 1}, which spells every case of
 // src/gas_optics_ecckd.f90:143-149 exactly: array/linear (1, 0); array/relative_linear (1, -ref);
 // scalar/linear (0, scalar); scalar/relative_linear (0, scalar - ref); none_ (0, 1); unused (0, 0).
@@ -98,6 +100,11 @@ struct RteLwArgs {
   double *scratch;             // generic-nlay path only
   int f32;                     // 1: the data pointers address float arrays
   int shared_levels;           // 1: lev_source_inc(:,l,:) == lev_source_dec(:,l+1,:): each level is read once
+  const double *inc_flux;      // (ncol,ng) incident diffuse flux at the top of the domain, or nullptr (none)
+  // version switches of the un-pinned RTE-RRTMGP solver (ecckd_set_solver_option)
+  double tau_thresh;           // lw_source_noscat: series below this optical depth (sqrt(epsilon) of the precision)
+  int series3;                 // 0: tau*(0.5 - tau/3) (v1.5), 1: tau*(0.5 + tau*(-1/3 + tau/8))
+  int inc_isotropic;           // 0: I_dn(top) = inc_flux/(2 pi w_k) per angle, 1: inc_flux/pi
 };
 
 struct RteSwArgs {
@@ -109,6 +116,9 @@ struct RteSwArgs {
   double *flux_up, *flux_dn, *flux_dir;   // flux_dir may be nullptr
   double *scratch;
   int exact_division;          // 1 (reference-order arithmetic mode): IEEE `/`; 0: reciprocal + Newton steps
+  // version switches (ecckd_set_solver_option)
+  double k_floor;              // lower bound of (gamma1-gamma2)(gamma1+gamma2) under the square root (1e-12)
+  int dir_clamp;               // 1: Rdir/Tdir energy clamps of later RTE-RRTMGP releases
 };
 
 // Host-side helpers -------------------------------------------------------------------------

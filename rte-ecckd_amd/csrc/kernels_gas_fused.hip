@@ -409,11 +409,16 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const int ip0 = pp.ip0;
       // Lanes this pass is responsible for: existing columns whose pressure index belongs to the slab
       // position of the pass (with a single position: every existing column).
-      const bool own = valid && ip0 >= pos_lo && ip0 <= pos_hi;
+      // (a lane whose pressure index lies outside the range the pre-pass found -- only a NaN pressure does
+      // that: min/max skip it -- is assigned to the nearest position and sends its wave down the slow path:
+      // its column comes out NaN like the oracle's, and no lane is ever dropped)
+      const int ipq = ipmin <= ipmax ? (ip0 < ipmin ? ipmin : (ip0 > ipmax ? ipmax : ip0)) : ip0;
+      const bool own = valid && ipq >= pos_lo && ipq <= pos_hi;
       if (!__any(own)) {   // nothing of this wave in this pass
         continue;
       }
-      const bool lowest = !__any(valid && ip0 < pos_lo);   // this is the pass of the wave's lowest lane
+      const bool lowest = !__any(valid && ipq < pos_lo);   // this is the pass of the wave's lowest lane
+      const bool stray_wave = __any(valid && (ipq != ip0 || ipmin > ipmax));
       // (lanes of other passes are carried along with a clamped row: finite values, never stored)
       int ipl = ip0 - 1 - slab_lo;
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
@@ -474,7 +479,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       // all) goes through the tables-from-global-memory path, all its lanes at once, in the pass of
       // its lowest lane.  Every other wave runs the item pipeline in each pass it owns lanes of:
       // all 64 lanes owned -> paired 16-byte stores, else the owned lanes store on their own.
-      const bool slow_wave = __any(valid && !(inwin && R >= 2 && slab_lo >= 0));
+      const bool slow_wave = __any(valid && !(inwin && R >= 2 && slab_lo >= 0)) || stray_wave;
       const bool fast = !slow_wave;
       const bool active = own && inslab;
       const bool masked_wave = !__all(active);
@@ -853,7 +858,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   for (int s = 0; s <= kTauPassGases; ++s) {
     const int k = s < kTauPassGases ? (s < t.nbil ? t.bil_seq[s] : -1) : t.lut;
     SlotArgs &o = a.slot[s];
-    o = SlotArgs{t.plev, 0, 0u, 0., 0.};   // unused slot: a harmless load, weight 0
+    o = SlotArgs{t.zero, 0, 0u, 0., 0.};   // unused slot or scalar gas: the load reads a zero word of the model
     if (k >= 0) {
       const SeqGas &e = t.seq[k];
       const bool arr = e.vmr != nullptr;

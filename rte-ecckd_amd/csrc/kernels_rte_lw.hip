@@ -82,7 +82,7 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #endif
 }
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   static_assert(NL > 0 && !(EXACT && OVER), "unrolled layer count; overflow only in the padded form");
   constexpr int kPF = prefetch_depth(NL);
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     return s_ < nl;
   };
   const real pi = (real)acos(-1.);
-  const real tau_thresh = sizeof(real) == 8 ? (real)1.4901161193847656e-08 : (real)3.4526698300124393e-04;   // sqrt(epsilon(1._wp))
+  const real tau_thresh = (real)a.tau_thresh;   // sqrt(epsilon(1._wp)) unless ecckd_set_solver_option moved it
   // layer / level walked s-th from the top lives at index l0 + s*lstep
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay;
   const long lstep = a.top_at_1 ? 1 : -1;
@@ -195,7 +195,12 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       const real sfc_src = P(a.sfc_source)[cc + (long)ncol * gg];
 
       // ---------------- down sweep ----------------
-      real I = real(0);   // no incident diffuse flux: radn_dn(top) = 0
+      // radn_dn(top): no incident diffuse flux, or inc_flux turned into an intensity
+      real I = real(0);
+      if (a.inc_flux) {
+        const real f = P(a.inc_flux)[cc + (long)ncol * gg];
+        I = a.inc_isotropic ? f / pi : f / (real(2) * pi * (real)a.wts[k]);
+      }
       auto layer = [&](int s, real tau, real lay, real bdn, real bup, real &t_out,
                        real &su_out) {
         const bool act = !PAD || present(s);
@@ -205,7 +210,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         const real omt = real(1) - t;
         // both branches of lw_source_noscat's merge() are evaluated and selected (no branch)
         const real fact_big = omt / tl - t;
-        const real fact_small = tl * (real(0.5) - real(1) / real(3) * tl);
+        const real fact_small = SER3 ? tl * (real(0.5) + tl * (-real(1) / real(3) + tl * (real(1) / real(8))))
+                                     : tl * (real(0.5) - real(1) / real(3) * tl);
         const real fact = tl > tau_thresh ? fact_big : fact_small;
         const real sdn = omt * bdn + real(2) * fact * (lay - bdn);
         real su = omt * bup + real(2) * fact * (lay - bup);
@@ -283,9 +289,9 @@ constexpr int kOverWaves = 2048;   // grid of the overflow variant (its scratch 
 constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
 constexpr int kOverCW = 16;   // 16 * (nlay + 2) * CW bytes of LDS accumulators per wave: 16 columns keep 4 waves per CU
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
-hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER, SHARED>;
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3>
+hipError_t launch_ser(const RteLwArgs &a, hipStream_t s) {
+  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER, SHARED, SER3>;
   const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + (EXACT ? 0 : 1)) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -295,6 +301,12 @@ hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
   if (OVER && tiles > kOverWaves) tiles = kOverWaves;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
   return hipGetLastError();
+}
+
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
+hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
+  return a.series3 ? launch_ser<real, NL, CW, EXACT, OVER, SHARED, true>(a, s)
+                   : launch_ser<real, NL, CW, EXACT, OVER, SHARED, false>(a, s);
 }
 
 template <typename real, bool SHARED>

@@ -62,8 +62,8 @@ __device__ __forceinline__ double rcp(double x) {
   r = fma(fma(-x, r, 1.), r, r);
   return r;
 }
-template <bool FAST>
-__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq, double mu0, double mu0_inv) {
+template <bool FAST, bool CLAMP>
+__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq, double mu0, double mu0_inv, double k_floor) {
   const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
   const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
   const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
@@ -72,7 +72,7 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
   const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
   const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
   const double kk0 = (gamma1 - gamma2) * (gamma1 + gamma2);
-  const double k = sqrt(kk0 > 1.e-12 ? kk0 : 1.e-12);
+  const double k = sqrt(kk0 > k_floor ? kk0 : k_floor);   // k_floor = 1e-12 unless ecckd_set_solver_option moved it
   const double exp_minusktau = exp(-tau * k);
   const double exp_minus2ktau = exp_minusktau * exp_minusktau;
   double RT_term = rcp<FAST>(k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
@@ -89,6 +89,11 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
   r.Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * r.Tnoscat -
                        (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * r.Tnoscat -
                        2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+  if (CLAMP) {   // later RTE-RRTMGP releases: the direct beam can neither gain energy nor go negative
+    const double lim = 1. - r.Tnoscat;
+    r.Rdir = fmax(0., fmin(r.Rdir, lim));
+    r.Tdir = fmax(0., fmin(r.Tdir, lim - r.Rdir));
+  }
   return r;
 }
 
@@ -98,7 +103,7 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
 // needs as well (24 + 48 + 48 = 120 B/cell).  The kernel is bound by that traffic, not by the
 // arithmetic (0.25 VALU wave-instr/clk/CU of 0.81 available at this occupancy): measured 4.52 ms
 // stored vs 3.85 ms recomputed per 1e5 columns x 27 g-points (recomputed: 52 % of the fp64 VALU rate).
-template <int CW, bool RECOMPUTE, bool FAST>
+template <int CW, bool RECOMPUTE, bool FAST, bool CLAMP>
 __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   constexpr int GW = 64 / CW;
   extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
@@ -117,6 +122,7 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
   double *sA = sSrc + 64L * nlev, *sB = sA + 64L * nlay, *sC = sB + 64L * nlay, *sTn = sC + 64L * nlay;
   const int ngroups = (ng + GW - 1) / GW;
   const long ntiles = ((long)ncol + CW - 1) / CW;
+  const double k_floor = a.k_floor;
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long col = tile * CW + cl;
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
           const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
           ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
         }
-        const TwoStream ts = two_stream<FAST>(ctau, cssa, cg, mu0, mu0_inv);
+        const TwoStream ts = two_stream<FAST, CLAMP>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
         const double denom = rcp<FAST>(1. - ts.Rdif * albedo);                             // adding, Eq 10
         if (!RECOMPUTE) {
           sA[64L * s] = ts.Tdif * denom;
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
         }
         double A, B, C, Tn;
         if (RECOMPUTE) {
-          const TwoStream ts = two_stream<FAST>(ctau, cssa, cg, mu0, mu0_inv);
+          const TwoStream ts = two_stream<FAST, CLAMP>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
           const double denom = rcp<FAST>(1. - ts.Rdif * alb_next);     // the same expression as in pass 1: same bits
           A = ts.Tdif * denom; B = ts.Rdif * denom; C = ts.Tdir * denom; Tn = ts.Tnoscat;
         } else {
@@ -268,7 +274,8 @@ size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   constexpr int CW = ECCKD_SW_CW;
-  auto k = a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false> : rte_sw_kernel<CW, kSwRecompute, true>;
+  auto k = a.dir_clamp ? (a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false, true> : rte_sw_kernel<CW, kSwRecompute, true, true>)
+                       : (a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false, false> : rte_sw_kernel<CW, kSwRecompute, true, false>);
   const size_t lds = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),

@@ -239,3 +239,11 @@ def test_gas_concs_mirror(pkg):
     src = pkg.SourceFuncLW(); src.alloc(3, 2, k)
     msg = k.gas_optics(None, np.ones((3, 3)), np.ones((2, 3)), np.ones(3), g2, op, src, tlev=np.ones((3, 3)))
     assert msg == "ty_gas_concs%get_vmr; gas h2o not found"     # get_vmr error is passed through (:351-354)
+
+
+def test_bench_default_shard_size_for_8_gpus():
+    """bench.py --gpus 8 runs BASELINE configs[3]: 1e7 columns in total, 1.25e6 per rank; fewer GPUs weak-scale the
+    1e6-column headline."""
+    import bench
+    assert bench.columns_per_gpu(8, None) == 1250000 and bench.columns_per_gpu(1, None) == 1000000
+    assert bench.columns_per_gpu(2, None) == 1000000 and bench.columns_per_gpu(4, 300000) == 300000

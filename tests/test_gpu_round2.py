@@ -1,0 +1,492 @@
+"""GPU parity tests added in round 2 (all through the C ABI, against the CPU oracle or against properties):
+
+  * node-identity known answers from the reference-held LUT files, on the HIP path;
+  * a NaN in one column stays in that column;
+  * incident-flux boundary condition of rte_lw and the solver version switches, HIP vs oracle;
+  * every ECCKD_DEVICE solver call is asynchronous: rte_sw and rte_lw with 137 layers captured in HIP graphs,
+    two streams running concurrently;
+  * BASELINE configs[4]: the 36-g-point table in fp32 against the fp64 oracle (tolerance sweep);
+  * BASELINE configs[3]: the 1.25e6-column per-rank shard of the 1e7-column job on one GPU.
+
+Tolerances as in test_gpu_parity.py: Planck sources bit-identical, tau 1e-12 relative, fluxes 1e-9 W m-2
+(north_star: 1e-6)."""
+import numpy as np
+import pytest
+
+import helpers
+from conftest import LW_FSCK, LW_RRTMGP, SW_WIDE
+from rte_ecckd_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+TAU_RTOL = 1e-12
+FLUX_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def lw(pkg, gpu, oracle_mod):
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_FSCK, device=0) == ""
+    return k, oracle_mod.CkdModel(LW_FSCK)
+
+
+@pytest.fixture(params=["fast", "reference_order"])
+def arithmetic(request, pkg):
+    pkg.set_arithmetic(pkg.FAST if request.param == "fast" else pkg.REFERENCE_ORDER)
+    yield request.param
+    pkg.set_arithmetic(pkg.FAST)
+
+
+@pytest.fixture(autouse=True)
+def default_options(pkg):
+    pkg.reset_solver_options()
+    yield
+    pkg.reset_solver_options()
+
+
+def T(gpu):
+    import torch
+    return lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def lw_objects(pkg, gpu, tau, lay, inc, dec, sfc, b2g=None):
+    import torch
+    t = T(gpu)
+    ng, nlay, ncol = tau.shape
+    op = pkg.OpticalProps1scl(); op.tau = t(tau)
+    op.band2gpt = np.array([[1, ng]], dtype=np.int32) if b2g is None else b2g
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    fl = pkg.FluxesBroadband(torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu),
+                             torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu))
+    return op, src, fl
+
+
+# ------------------------------------------------------------------------------------------------
+# node identities -- "parity unpinned" still holds: these tie the HIP path to numbers
+# the reference's own data files hold, not to a run of the reference code
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", [LW_FSCK, LW_RRTMGP])
+def test_planck_sources_on_table_nodes(pkg, gpu, oracle_mod, path, arithmetic):
+    k = pkg.GasOpticsEcckd()
+    assert k.load(path, device=0) == ""
+    m = oracle_mod.CkdModel(path)
+    cols, want = helpers.planck_node_case(m)
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu, names=[])
+    assert err == ""
+    assert np.array_equal(sfc, want)
+    for a in (lay, inc, dec):
+        assert np.array_equal(a, np.repeat(want[:, None, :], 3, 1))
+    assert np.all(tau == 0)      # empty gas list: tau is zeroed (:346)
+
+
+def test_tau_on_table_nodes(pkg, gpu, oracle_mod, arithmetic):
+    """tau == weight * coefficient(:,ip,it) on exact table nodes.  Reference-order arithmetic: bit for bit
+    (weights are exactly 1 and 0); fast arithmetic multiplies the weights out first -- still exact here."""
+    import torch
+    t = T(gpu)
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_FSCK, device=0) == ""
+    m = oracle_mod.CkdModel(LW_FSCK)
+    for name, cols, item, want in helpers.tau_node_cases(m):
+        err, tau = helpers.run_lw_gas_optics(pkg, k, cols, gpu, names=[name], overrides={name: float(item[1][0])})[:2]
+        assert err == ""
+        if name == "h2o":    # the device log() of the first mole-fraction node may sit one ulp off the host's
+            assert helpers.max_rel(tau, want) < 1e-13, name
+        else:
+            assert np.array_equal(tau, want), name
+    ks = pkg.GasOpticsEcckd()
+    assert ks.load(SW_WIDE, device=0) == ""
+    ms = oracle_mod.CkdModel(SW_WIDE)
+    for name, cols, item, want in helpers.tau_node_cases(ms):
+        ncol = cols["plev"].shape[1]
+        gc = pkg.GasConcs([name]); gc.set_vmr(name, float(item[1][0]))
+        op = pkg.OpticalProps2str(); op.alloc_2str(ncol, 1, ks, like=t(np.zeros(1)))
+        toa = torch.empty((ms.ng, ncol), dtype=torch.float64, device=gpu)
+        assert ks.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), gc, op, toa) == ""
+        ray = helpers.GLOBAL_WEIGHT * (cols["plev"][1] - cols["plev"][0])[None, None, :] * ms.rayleigh[:, None, None]
+        if name == "h2o":
+            assert helpers.max_rel(op.tau.cpu().numpy(), want + ray) < 1e-13, name
+        else:
+            assert np.array_equal(op.tau.cpu().numpy(), want + ray), name
+        assert np.array_equal(toa.cpu().numpy(), np.repeat(ms.solar_irradiance[:, None], ncol, 1))
+
+
+def test_nan_stays_in_its_own_column(pkg, gpu, oracle_mod, lw, arithmetic):
+    """a NaN in one column's inputs (pressure, temperature, a gas array -- or the one element the
+    unused gas slots used to read) must poison that column only, and no column may be left unwritten."""
+    k, m = lw
+    ncol = 700
+    cols = synthetic.columns(11, ncol, k.get_press_min())
+    cols = {n: (v.copy() if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+    bad = {0: "plev", 65: "plev", 130: "tlay", 257: "h2o", 300: "co2", 699: "plev"}
+    cols["plev"][7, 0] = np.nan          # (level 8 of column 0: the element every dummy slot load used to read at j = 7)
+    cols["plev"][:, 65] = np.nan
+    cols["tlay"][3, 130] = np.nan
+    cols["h2o"][40, 257] = np.nan
+    cols["co2"][300] = np.nan
+    cols["plev"][60, 699] = np.nan
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    assert err == ""
+    otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                               helpers.oracle_gas_items(cols), cols["tlev"])
+    good = np.ones(ncol, dtype=bool)
+    good[list(bad)] = False
+    assert np.all(np.isfinite(tau[..., good])) and np.all(np.isfinite(lay[..., good]))
+    assert helpers.max_rel(tau[..., good], otau[..., good]) < TAU_RTOL
+    assert np.array_equal(lay[..., good], olay[..., good]) and np.array_equal(inc[..., good], oinc[..., good])
+    assert np.array_equal(np.isnan(tau), np.isnan(otau))           # NaN exactly where the oracle has it
+    assert np.array_equal(np.isnan(lay), np.isnan(olay))
+    ok = ~np.isnan(otau)
+    assert helpers.max_rel(tau[ok], otau[ok]) < TAU_RTOL
+
+
+def test_unknown_gas_needs_no_concentration(pkg, gpu, oracle_mod, lw):
+    """The reference only consults get_vmr for gases of the k-distribution (:348-364): a gas_desc naming an
+    unknown gas that was never set is not an error."""
+    k, m = lw
+    cols = synthetic.columns(0, 70, k.get_press_min())
+    t = T(gpu)
+    gc = pkg.GasConcs(["co2", "xyz", "h2o"])
+    assert gc.set_vmr("co2", 4e-4) == "" and gc.set_vmr("h2o", t(cols["h2o"])) == ""     # "xyz" never set
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(70, 60, k, like=t(np.zeros(1)))
+    src = pkg.SourceFuncLW(); src.alloc(70, 60, k, like=t(np.zeros(1)))
+    assert k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), t(cols["tsfc"]), gc, op, src, tlev=t(cols["tlev"])) == ""
+    otau = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                     [("co2", np.array([4e-4]), 0, 0), ("h2o", cols["h2o"], 1, 70)], cols["tlev"])[0]
+    assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
+    gc2 = pkg.GasConcs(["co2", "h2o"]); gc2.set_vmr("co2", 4e-4)                          # a KNOWN gas that was never set
+    assert "h2o" in k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), t(cols["tsfc"]), gc2, op, src, tlev=t(cols["tlev"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# incident flux + solver switches
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nlay,top_at_1,nmus", [(60, True, 1), (60, False, 3), (33, True, 2), (137, False, 1)])
+def test_rte_lw_incident_flux(pkg, gpu, oracle_mod, nlay, top_at_1, nmus):
+    rng = np.random.default_rng(nlay)
+    ng, ncol = 6, 130
+    tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (ng, ncol)); emis = rng.uniform(0.7, 1.0, (ncol, 1))
+    incf = rng.uniform(0, 30, (ng, ncol))
+    t = T(gpu)
+    op, src, fl = lw_objects(pkg, gpu, tau, lay, inc, dec, sfc)
+    emis_gpt = np.repeat(emis.T, ng, 0)
+    for iso in (0, 1):
+        pkg.set_solver_option("lw_inc_flux_isotropic", iso)
+        assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus, inc_flux=t(incf)) == ""
+        fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, emis_gpt, sfc, top_at_1=top_at_1, nmus=nmus, inc_flux=incf,
+                                   options=oracle_mod.solver_options(lw_inc_flux_isotropic=iso))
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+    top = 0 if top_at_1 else nlay
+    assert np.allclose(fl.flux_dn.cpu().numpy()[top], incf.sum(0), rtol=1e-9)        # isotropic: the flux comes back
+    # host memory space: the same numbers; NULL inc_flux: the plain solver
+    op_h = pkg.OpticalProps1scl(); op_h.tau = tau; op_h.band2gpt = op.band2gpt
+    s_h = pkg.SourceFuncLW(); s_h.lay_source, s_h.lev_source_inc, s_h.lev_source_dec, s_h.sfc_source = lay, inc, dec, sfc
+    fl_h = pkg.FluxesBroadband(np.empty((nlay + 1, ncol)), np.empty((nlay + 1, ncol)))
+    assert pkg.rte_lw(op_h, top_at_1, s_h, np.ascontiguousarray(emis), fl_h, n_gauss_angles=nmus, inc_flux=incf) == ""
+    assert np.array_equal(fl_h.flux_dn, fl.flux_dn.cpu().numpy())
+    # analytic: transparent column, F_dn = sum_g inc_flux at every level
+    z = np.zeros_like(tau)
+    opz, srcz, flz = lw_objects(pkg, gpu, z, z, z, z, np.zeros((ng, ncol)))
+    pkg.reset_solver_options()
+    assert pkg.rte_lw(opz, top_at_1, srcz, t(np.ones((ncol, 1))), flz, n_gauss_angles=1, inc_flux=t(incf)) == ""
+    assert np.allclose(flz.flux_dn.cpu().numpy(), incf.sum(0)[None, :], rtol=1e-14)
+    assert np.all(flz.flux_up.cpu().numpy() == 0)
+
+
+def test_lw_solver_switches(pkg, gpu, oracle_mod):
+    rng = np.random.default_rng(5)
+    ng, nlay, ncol = 5, 60, 200
+    tau = rng.uniform(0, 1, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-5, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (ng, ncol)); emis = rng.uniform(0.7, 1.0, (ncol, 1))
+    t = T(gpu)
+    op, src, fl = lw_objects(pkg, gpu, tau, lay, inc, dec, sfc)
+    emis_gpt = np.repeat(emis.T, ng, 0)
+    outs = []
+    for thresh, terms in ((0.0, 2), (1.220703125e-4, 3), (1e-2, 2), (1e-2, 3)):
+        pkg.set_solver_option("lw_tau_thresh", thresh); pkg.set_solver_option("lw_series_terms", terms)
+        assert pkg.get_solver_option("lw_series_terms") == terms
+        assert pkg.rte_lw(op, True, src, t(emis), fl) == ""
+        kw = dict(lw_series_terms=terms)
+        if thresh > 0:
+            kw["lw_tau_thresh"] = thresh
+        fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, emis_gpt, sfc, options=oracle_mod.solver_options(**kw))
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+        outs.append(fl.flux_dn.cpu().numpy().copy())
+    assert not np.array_equal(outs[2], outs[3])         # the switch does switch
+    with pytest.raises(ValueError):
+        pkg.set_solver_option("lw_series_terms", 4)
+    with pytest.raises(ValueError):
+        pkg.set_solver_option("no_such_option", 1)
+
+
+def test_sw_solver_switches(pkg, gpu, oracle_mod, arithmetic):
+    import torch
+    rng = np.random.default_rng(6)
+    ng, nlay, ncol = 7, 60, 300
+    tau = rng.uniform(0.001, 3.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.999999, (ng, nlay, ncol))
+    g = rng.uniform(0, 0.9, (ng, nlay, ncol))
+    ssa[:, :, :40] = 1.0; g[:, :, :40] = 0.0             # conservative scattering: k*k hits the floor
+    mu0 = rng.uniform(0.05, 1.0, ncol); toa = rng.uniform(10, 100, (ng, ncol))
+    alb = rng.uniform(0.05, 0.4, (ncol, 1))
+    t = T(gpu)
+    op = pkg.OpticalProps2str(); op.tau, op.ssa, op.g = t(tau), t(ssa), t(g)
+    op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+    fl = pkg.FluxesBroadband(*(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3)))
+    a_gpt = np.repeat(alb.T, ng, 0)
+    res = {}
+    for clamp, kfl in ((0, 1e-12), (1, 1e-12), (0, 2.2e-12), (1, 1e-6)):
+        pkg.set_solver_option("sw_dir_clamp", clamp); pkg.set_solver_option("sw_k_floor", kfl)
+        assert pkg.rte_sw(op, True, t(mu0), t(toa), t(alb), t(alb), fl) == ""
+        fu, fd, fdir = oracle_mod.rte_sw(tau, ssa, g, mu0, toa, a_gpt, a_gpt,
+                                         options=oracle_mod.solver_options(sw_dir_clamp=clamp, sw_k_floor=kfl))
+        scale = max(1.0, float(np.max(np.abs(fu))))
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < FLUX_ATOL * scale
+        assert np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL * scale
+        assert np.max(np.abs(fl.flux_dn_dir.cpu().numpy() - fdir)) < FLUX_ATOL * scale
+        res[(clamp, kfl)] = fl.flux_up.cpu().numpy().copy()
+    assert not np.array_equal(res[(0, 1e-12)], res[(1, 1e-12)])
+
+
+# ------------------------------------------------------------------------------------------------
+# ECCKD_DEVICE is asynchronous for every solver
+# ------------------------------------------------------------------------------------------------
+def _sw_case(pkg, gpu, rng, ncol, nlay=60, ng=9):
+    import torch
+    t = T(gpu)
+    tau = rng.uniform(0.001, 2.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.99, (ng, nlay, ncol)); g = rng.uniform(0, 0.8, (ng, nlay, ncol))
+    op = pkg.OpticalProps2str(); op.tau, op.ssa, op.g = t(tau), t(ssa), t(g)
+    op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+    mu0 = t(rng.uniform(0.1, 1.0, ncol)); toa = t(rng.uniform(10, 100, (ng, ncol))); alb = t(rng.uniform(0.05, 0.4, (ncol, 1)))
+    fl = pkg.FluxesBroadband(*(torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3)))
+    return op, mu0, toa, alb, fl
+
+
+def test_rte_sw_and_deep_rte_lw_in_hip_graphs(pkg, gpu):
+    """rte_sw (always uses a scratch ring) and rte_lw with 137 layers (scratch ring beyond 96 layers) captured in
+    HIP graphs after one warm-up call on the capturing stream; a capture that would have to allocate fails with
+    a message instead of invalidating the capture silently; a caller-owned scratch buffer needs no warm-up."""
+    import torch
+    rng = np.random.default_rng(8)
+    ncol = 512
+    op, mu0, toa, alb, fl = _sw_case(pkg, gpu, rng, ncol)
+    nlay = 137
+    tau = rng.uniform(0, 1, (5, nlay, ncol)); lay, inc, dec = (rng.uniform(1, 9, (5, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (5, ncol))
+    op_l, src_l, fl_l = lw_objects(pkg, gpu, tau, lay, inc, dec, sfc)
+    emis = T(gpu)(np.full((ncol, 1), 0.97))
+
+    def step():
+        assert pkg.rte_sw(op, True, mu0, toa, alb, alb, fl) == ""
+        assert pkg.rte_lw(op_l, True, src_l, emis, fl_l) == ""
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                   # warm-up on the stream that will be captured: its scratch block exists now
+    torch.cuda.synchronize()
+    ref = (fl.flux_up.clone(), fl_l.flux_up.clone())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    fl.flux_up.zero_(); fl_l.flux_up.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(fl.flux_up, ref[0]) and torch.equal(fl_l.flux_up, ref[1])
+    # a stream that has never run the solver: capturing fails cleanly, with the remedy in the message
+    fresh = torch.cuda.Stream()
+    g2 = torch.cuda.CUDAGraph()
+    msg = None
+    try:
+        with torch.cuda.graph(g2, stream=fresh):
+            msg = pkg.rte_sw(op, True, mu0, toa, alb, alb, fl)
+    except RuntimeError:
+        pass                                     # torch may refuse to end an empty capture; the message is what matters
+    assert msg is not None and "captured" in msg and "ecckd_set_stream_scratch" in msg
+    # caller-owned scratch: no warm-up needed
+    fresh2 = torch.cuda.Stream()
+    need = max(pkg.rte_sw_scratch_bytes(ncol, 60, 9), pkg.rte_lw_scratch_bytes(ncol, nlay, 5))
+    assert need > 0 and pkg.rte_lw_scratch_bytes(ncol, 60, 32) == 0
+    buf = torch.empty(need, dtype=torch.uint8, device=gpu)
+    pkg.set_stream_scratch(buf, stream=fresh2)
+    g3 = torch.cuda.CUDAGraph()
+    fl.flux_up.zero_(); fl_l.flux_up.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g3, stream=fresh2):
+        step()
+    g3.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(fl.flux_up, ref[0]) and torch.equal(fl_l.flux_up, ref[1])
+    small = torch.empty(1024, dtype=torch.uint8, device=gpu)
+    pkg.set_stream_scratch(small, stream=fresh2)
+    with torch.cuda.stream(fresh2):
+        assert "too small" in pkg.rte_sw(op, True, mu0, toa, alb, alb, fl)
+    pkg.set_stream_scratch(None, stream=fresh2)
+    del g3, graph
+    pkg.release_scratch(0)
+
+
+def test_two_streams_run_the_solvers_concurrently(pkg, gpu, oracle_mod):
+    """Calls on different streams use different scratch blocks: interleaved launches of different problems on two
+    streams give the same fluxes as running each alone (a shared ring would be overwritten mid-flight)."""
+    import torch
+    rng = np.random.default_rng(9)
+    cases = [_sw_case(pkg, gpu, rng, 40000), _sw_case(pkg, gpu, rng, 37000)]
+    alone = []
+    for op, mu0, toa, alb, fl in cases:
+        assert pkg.rte_sw(op, True, mu0, toa, alb, alb, fl) == ""
+        torch.cuda.synchronize()
+        alone.append(fl.flux_up.clone())
+        fl.flux_up.zero_()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for s, (op, mu0, toa, alb, fl) in zip(streams, cases):
+            with torch.cuda.stream(s):
+                assert pkg.rte_sw(op, True, mu0, toa, alb, alb, fl) == ""
+    torch.cuda.synchronize()
+    for want, (_, _, _, _, fl) in zip(alone, cases):
+        assert torch.equal(fl.flux_up, want)
+    # spot check against the oracle
+    op, mu0, toa, alb, fl = cases[1]
+    sl = slice(0, 64)
+    a = np.repeat(alb.cpu().numpy()[sl].T, 9, 0)
+    fu, _, _ = oracle_mod.rte_sw(op.tau[..., sl].cpu().numpy(), op.ssa[..., sl].cpu().numpy(), op.g[..., sl].cpu().numpy(),
+                                 mu0[sl].cpu().numpy(), toa[:, sl].cpu().numpy(), a, a)
+    assert np.max(np.abs(fl.flux_up[:, sl].cpu().numpy() - fu)) < FLUX_ATOL
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: 36-g-point table, fp32 vs fp64 tolerance sweep
+# ------------------------------------------------------------------------------------------------
+def test_lw_36g_fp32_against_fp64_oracle(pkg, gpu, oracle_mod):
+    """LW rrtmgp-tol0.061 (36 g-points, 16 bands; the higher-g file present in the reference: SURVEY section 8(c) 'Data
+    gap'), 1000 columns: the fp64 path against the fp64 oracle at the fp64 bars, the fp32 path (float arrays: a host
+    built with wp = real32; the Planck window is active because the 36-g table does not fit LDS whole in fp64 and is
+    staged whole in fp32) against the same oracle at the stated single-precision bars:
+        tau 2e-5 relative (where tau > 1e-6 max), sources 2e-6 relative, fluxes 2e-3 W m-2."""
+    import torch
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_RRTMGP, device=0) == ""
+    m = oracle_mod.CkdModel(LW_RRTMGP)
+    ncol, nlay, ng = 1000, 60, 36
+    assert k.get_ngpt() == ng and k.get_nband() == 16
+    cols = synthetic.columns(17, ncol, k.get_press_min())
+    emis2 = np.repeat(cols["sfc_emis"][:, None], 16, 1) * np.linspace(0.9, 1.0, 16)[None, :]
+    emis_gpt = np.ascontiguousarray(emis2[:, m.gpt2band - 1].T)
+    report = {}
+    for name, npdt, tdt in (("f64", np.float64, torch.float64), ("f32", np.float32, torch.float32)):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=npdt)).to(gpu)
+        gc = pkg.GasConcs(synthetic.GAS_ORDER)
+        for n in synthetic.GAS_ORDER:
+            v = cols[n]
+            if np.isscalar(v):
+                gc.set_vmr(n, float(v))
+            elif v.ndim == 1:
+                gc.set_vmr_column(n, t(v))
+            else:
+                gc.set_vmr(n, t(v))
+        plev = t(cols["plev"])
+        op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=plev)
+        src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k, like=plev)
+        assert k.gas_optics(None, plev, t(cols["tlay"]), t(cols["tsfc"]), gc, op, src, tlev=t(cols["tlev"])) == ""
+        fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=tdt, device=gpu), torch.empty((nlay + 1, ncol), dtype=tdt, device=gpu))
+        assert pkg.rte_lw(op, True, src, t(emis2), fl) == ""
+        # the oracle sees the inputs as this precision rounds them, and computes in double
+        r = lambda a: np.ascontiguousarray(np.asarray(a, dtype=npdt), dtype=np.float64)
+        c = {n: (r(v) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+        tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, c["plev"], c["tlay"], c["tsfc"], helpers.oracle_gas_items(c), c["tlev"])
+        fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, r(emis_gpt), sfc)
+        gt = op.tau.cpu().numpy().astype(np.float64)
+        big = tau > 1e-6 * tau.max()
+        report[name] = dict(tau=float(np.max(np.abs(gt - tau)[big] / tau[big])),
+                            src=max(helpers.max_rel(src.lay_source.cpu().numpy(), lay), helpers.max_rel(src.lev_source_inc.cpu().numpy(), inc),
+                                    helpers.max_rel(src.sfc_source.cpu().numpy(), sfc)),
+                            flux=max(float(np.max(np.abs(fl.flux_up.cpu().numpy() - fu))), float(np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)))))
+    print("configs[4] sweep, 36 g-points:", report)
+    assert report["f64"]["tau"] < TAU_RTOL and report["f64"]["src"] == 0.0 and report["f64"]["flux"] < FLUX_ATOL
+    assert report["f32"]["tau"] < 2e-5 and report["f32"]["src"] < 2e-6 and report["f32"]["flux"] < 2e-3
+    plan = k.plan(ncol, nlay, synthetic.GAS_ORDER, single_precision=True)
+    assert plan["fused"] == 1 and plan["planck_fused"] == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: one rank's shard of the 1e7-column job
+# ------------------------------------------------------------------------------------------------
+def test_configs3_shard_properties(pkg, gpu, oracle_mod, lw):
+    """1e7 columns sharded over 8 GPUs = 1.25e6 columns per rank (77 GB of intermediates).  The LAST rank's shard
+    (columns 8 750 000 .. 9 999 999 of the counter-based generator) on one GPU: oracle spot checks at both ends and
+    in the middle, then properties the full size allows -- determinism, exact linearity of rte_lw in the sources,
+    zero incident flux, and the shard boundary: its first columns equal the last columns of a run that straddles
+    the boundary (column-range sharding is exact)."""
+    import torch
+    k, m = lw
+    ncol, nlay, ng = 1250000, 60, 32
+    c0 = 7 * ncol
+    f64 = dict(dtype=torch.float64, device=gpu)
+    d = {n: torch.empty((nlay + 1 if n in ("plev", "tlev") else nlay, ncol), **f64) for n in ("plev", "tlev", "tlay", "h2o", "o3")}
+    pc = {n: torch.empty((ncol,), **f64) for n in ("tsfc", "sfc_emis", "co2", "ch4", "n2o", "cfc11", "cfc12")}
+    keep = {}
+    for s0 in range(0, ncol, 125000):
+        cols = synthetic.columns(c0 + s0, 125000, k.get_press_min())
+        for n in d:
+            d[n][:, s0:s0 + 125000] = torch.from_numpy(cols[n]).to(gpu)
+        for n in pc:
+            pc[n][s0:s0 + 125000] = torch.from_numpy(cols[n]).to(gpu)
+        if s0 in (0, 625000, ncol - 125000):
+            keep[s0] = cols
+    gc = pkg.GasConcs(synthetic.GAS_ORDER)
+    for n in synthetic.GAS_ORDER:
+        if n in d:
+            gc.set_vmr(n, d[n])
+        elif n in pc:
+            gc.set_vmr_column(n, pc[n])
+        else:
+            gc.set_vmr(n, 0.209 if n == "o2" else 0.0)
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=d["plev"])
+    src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k, like=d["plev"])
+    fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), **f64), torch.empty((nlay + 1, ncol), **f64))
+    emis = pc["sfc_emis"].reshape(ncol, 1)
+
+    def run():
+        assert k.gas_optics(None, d["plev"], d["tlay"], pc["tsfc"], gc, op, src, tlev=d["tlev"]) == ""
+        assert pkg.rte_lw(op, True, src, emis, fl) == ""
+        torch.cuda.synchronize()
+
+    run()
+    for s0, sl in ((0, slice(0, 96)), (625000, slice(625000, 625096)), (ncol - 125000, slice(ncol - 96, ncol))):
+        cols = keep[s0]
+        lo = sl.start - s0
+        sub = {n: (np.ascontiguousarray(v[..., lo:lo + 96]) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+        otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, sub["plev"], sub["tlay"], sub["tsfc"], synthetic.gas_items(sub), sub["tlev"])
+        fu, fd = oracle_mod.rte_lw(otau, olay, oinc, odec, np.repeat(sub["sfc_emis"][None], ng, 0), osfc)
+        assert helpers.max_rel(op.tau[..., sl].cpu().numpy(), otau) < TAU_RTOL
+        assert np.array_equal(src.lay_source[..., sl].cpu().numpy(), olay)
+        assert np.array_equal(src.lev_source_dec[..., sl].cpu().numpy(), odec)
+        assert np.max(np.abs(fl.flux_up[:, sl].cpu().numpy() - fu)) < FLUX_ATOL
+        assert np.max(np.abs(fl.flux_dn[:, sl].cpu().numpy() - fd)) < FLUX_ATOL
+    assert bool(torch.all(fl.flux_dn[0] == 0))
+    assert bool(torch.all(torch.isfinite(fl.flux_up))) and bool(torch.all(fl.flux_up > 0))
+    ref_up, ref_dn = fl.flux_up.clone(), fl.flux_dn.clone()
+    tau_sum = op.tau.sum(dtype=torch.float64).item()
+    # determinism
+    fl.flux_up.zero_(); fl.flux_dn.zero_()
+    run()
+    assert torch.equal(fl.flux_up, ref_up) and torch.equal(fl.flux_dn, ref_dn) and op.tau.sum(dtype=torch.float64).item() == tau_sum
+    # linearity of rte_lw in the sources: x2 is exact in binary floating point
+    for a in (src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source):
+        a.mul_(2.0)
+    assert pkg.rte_lw(op, True, src, emis, fl) == ""
+    torch.cuda.synchronize()
+    assert torch.equal(fl.flux_up, 2.0 * ref_up) and torch.equal(fl.flux_dn, 2.0 * ref_dn)
+    # shard boundary: a 4096-column run that straddles it (2048 columns of rank 6, 2048 of rank 7)
+    n2 = 4096
+    cb = synthetic.columns(c0 - 2048, n2, k.get_press_min())
+    err, tau_b, lay_b, inc_b, dec_b, sfc_b = helpers.run_lw_gas_optics(pkg, k, cb, gpu)
+    assert err == ""
+    assert np.array_equal(tau_b[..., 2048:], op.tau[..., :2048].cpu().numpy())

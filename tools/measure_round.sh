@@ -7,9 +7,9 @@ tag=$1
 export TMPDIR=/tmp
 o=gpurun_out
 python bench.py --steps 10 --warmup 2 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --host-sample 0 > $o/${tag}_bench_prof.json 2> $o/${tag}_bench_prof.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --host-sample 0 > /dev/null 2> $o/${tag}_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --host-sample 0 > /dev/null 2> $o/${tag}_pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-side > $o/${tag}_bench_prof.json 2> $o/${tag}_bench_prof.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-side > /dev/null 2> $o/${tag}_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-side > /dev/null 2> $o/${tag}_pmc_write.err
 python tools/pmc_traffic.py $o/${tag}_pmc_fetch $o/${tag}_pmc_write "synthetic 1000000 columns x 60 layers x 32 g-points per GPU, LW fsck-tol0.0161" > $o/${tag}_hbm_traffic.json
 python bench.py --mode sw --ncol 100000 --steps 10 --warmup 2 --cpu-seconds 0 > $o/${tag}_bench_sw.json 2> $o/${tag}_bench_sw.err
 python bench.py --dtype f32 --steps 10 --warmup 2 --cpu-seconds 0 > $o/${tag}_bench_f32.json 2> $o/${tag}_bench_f32.err

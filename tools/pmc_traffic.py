@@ -19,7 +19,7 @@ def per_kernel(d, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = row["Kernel_Name"]
-            for key in ("gas_fused_kernel", "rte_lw_kernel", "rte_sw_kernel", "tau_kernel", "planck_kernel"):   # noqa: E501
+            for key in ("gas_fused_kernel", "rte_lw_kernel", "rte_sw_kernel", "tau_kernel", "planck_kernel", "rte_lw_split_kernel"):   # noqa: E501
                 if key in name:
                     if key == "gas_fused_kernel" and "<float" in name:
                         key = "gas_fused_kernel_f32"
@@ -37,7 +37,11 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                "reads = 2 * FETCH_SIZE * 1024 (gfx950 counts 128-B requests as 64 B; calibrated on rte_lw_kernel, "
                "whose read set is 4 arrays of ncol*60*32 doubles + sfc_source + emis), writes = WRITE_SIZE * 1024 "
                "(tools/pmc_traffic.py)",
-       "workload": sys.argv[3], "kernels": {}}
+       "workload": sys.argv[3], "kernel_sha": None, "kernels": {}}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out["kernel_sha"] = bench.kernel_source_sha()   # bench.py quotes this file only for the build it was measured on
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out["kernels"][names[k]] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
