@@ -126,6 +126,54 @@ def cpu_baseline(args, press_min):
     return out
 
 
+def fortran_device_resident(pkg, lw_file, n, press_min, ng):
+    """The reference-language path at the GPU's rate: the Fortran driver (rte-ecckd_amd/fortran/ecckd_driver.F90, the
+    block loop of ecckd_rfmip_lw.F90:107-136 over the drop-in module) with the device-resident twins of optical_props /
+    source (ECCKD_MIXED: the atmosphere goes in, the fluxes come out, tau and the sources stay in HBM), all columns in
+    one block, against the same driver with host containers (ECCKD_HOST).  Wall time of the loop, best of 3, PCIe
+    transfers included -- a PCIe-bound figure, reported beside the headline, never as it."""
+    import struct
+    import subprocess
+    import tempfile
+    from rte_ecckd_amd import synthetic
+    drv = pkg.FORTRAN_DRIVER
+    if not os.path.exists(drv):
+        return {"skipped": "no Fortran driver binary (amdflang missing at build time)"}
+    cols = synthetic.columns(0, n, press_min)
+    names = synthetic.GAS_ORDER
+    nlay = NLAY
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(inp, "wb") as f:
+            f.write(struct.pack("<iii", n, nlay, len(names)))
+            for nm in names:
+                f.write(nm.encode().ljust(32, b" "))
+            for key in ("plev", "tlev", "tlay", "tsfc", "sfc_emis"):
+                f.write(np.ascontiguousarray(cols[key], dtype="<f8").tobytes())
+            for nm in names:
+                v = cols[nm]
+                full = np.broadcast_to(np.float64(v) if np.isscalar(v) else np.asarray(v, dtype=np.float64), (nlay, n))
+                f.write(np.ascontiguousarray(full, dtype="<f8").tobytes())
+        res = {}
+        for label, dev in (("device_resident", "1"), ("host_arrays", "0")):
+            nn = n if dev == "1" else min(n, 20000)
+            r = subprocess.run([drv, "lw", lw_file, inp, outp, str(nn), "1", dev, "3"], capture_output=True, text=True)
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            secs = None
+            for line in r.stderr.splitlines():
+                if "loop_seconds" in line:
+                    secs = float(line.split()[-1])
+            blocks = (n + nn - 1) // nn
+            res[label] = {"value": n * nlay * ng / secs / 1e6, "unit": "Mcol*lay*gpt/s", "loop_seconds": secs,
+                          "ncol": n, "block": nn, "blocks": blocks}
+        a = np.fromfile(outp, dtype="<f8")
+    res["note"] = ("Fortran ecckd%gas_optics + rte_lw through the type-bound API; device_resident: mo_ecckd_device twins, "
+                   "about 5 KB per column in and 1 KB out over PCIe, pageable host memory; host_arrays: the reference's "
+                   "calling convention, 64 B per cell out and back in")
+    return res
+
+
 class LwCase:
     """Device-resident inputs, intermediates and outputs of one LW gas_optics + rte_lw workload (columns
     c0 .. c0+ncol-1 of the counter-based synthetic generator) and the step that runs it."""
@@ -214,6 +262,9 @@ def main():
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling passes)")
+    ap.add_argument("--fortran-sample", type=int, default=200000,
+                    help="columns of the side measurement through the Fortran type-bound API in device-resident mode "
+                         "(ecckd_driver: host arrays in, fluxes out, tau and sources stay in HBM; 0 = skip)")
     args = ap.parse_args()
     if args.mode == "sw":
         if args.ncol is None:
@@ -381,6 +432,58 @@ def main():
                 "pipeline_value": cells_per_gpu / ((ms_gas + ms_sh) * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s",
                 "fluxes_bit_identical_to_generic_solver": identical,
                 "note": "opt-in entry point; the headline value uses the generic ecckd_rte_lw, which reads both level arrays"}
+        # Side measurements on the same resident inputs: (a) the layer-split longwave solver behind the same API; (b) the
+        # fused longwave path -- gas optics writes tau only, the solver recomputes the Planck sources (16 instead of
+        # 64 B/cell between the kernels; bound by fp64 issue, not HBM: reported apart from the API-boundary roofline).
+        out["lw_solver_variants"] = None
+        out["fused_lw"] = None
+        if side and args.dtype == "f64" and args.arithmetic == "fast":
+            saved = pkg.get_solver_option("lw_solver")
+            var = {}
+            for label, sel, seg in (("register_resident", 0, 10), ("layer_split_seg10", 1, 10), ("layer_split_seg12", 1, 12),
+                                    ("layer_split_seg15", 1, 15)):
+                pkg.set_solver_option("lw_solver", sel); pkg.set_solver_option("lw_split_seg", seg)
+                for _ in range(2):
+                    pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1)
+                torch.cuda.synchronize()
+                var[label] = {"rte_lw_ms": (time.perf_counter() - t0) / args.steps * 1e3}
+            pkg.set_solver_option("lw_solver", saved); pkg.set_solver_option("lw_split_seg", 10)
+            out["lw_solver_variants"] = var
+            if nlay == 60:
+                ref_up, ref_dn = fl.flux_up.clone(), fl.flux_dn.clone()
+                tsfc_d = case.percol["tsfc"]
+
+                def fstep():
+                    e = k.lw_fluxes(case.plev, case.tlay, tsfc_d, case.tlev, case.gc, True, emis, fl, n_gauss_angles=1)
+                    if e:
+                        raise SystemExit(e)
+                del src          # the fused path needs no source arrays: free 46 GB before tau scratch is taken
+                case.src = None
+                torch.cuda.empty_cache()
+                for _ in range(max(args.warmup, 1)):
+                    fstep()
+                torch.cuda.synchronize()
+                L.ecckd_prof_enable(1)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fstep()
+                torch.cuda.synchronize()
+                ms_f = (time.perf_counter() - t0) / args.steps * 1e3
+                L.ecckd_prof_enable(0)
+                kf = prof_report(L)
+                dmax = max(float((fl.flux_up - ref_up).abs().max()), float((fl.flux_dn - ref_dn).abs().max()))
+                out["fused_lw"] = {
+                    "value": cells_per_gpu / (ms_f * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": ms_f,
+                    "speedup_vs_headline": ms_per_step / ms_f, "kernels_avg_ms": {n: v[0] for n, v in kf.items()},
+                    "hbm_bytes_per_cell_between_kernels": 16, "bound": "fp64 VALU issue (not HBM): not quoted against the HBM roofline",
+                    "max_abs_flux_diff_vs_api_path_Wm2": dmax,
+                    "note": "ecckd_lw_fluxes: ecckd_gas_optics_lw_tau + ecckd_rte_lw_fused; same inputs, same fluxes"}
+                src = None
+                pkg.release_scratch(local_rank)
         del case, fl, op, src, emis
         torch.cuda.empty_cache()
         # BASELINE configs[1] (the same workload at 1e5 columns) and one rank's shard of configs[3] (1e7 columns over
@@ -429,6 +532,9 @@ def main():
             out["host_memspace"] = {"value": n * nlay * ng / best / 1e6, "unit": "Mcol*lay*gpt/s", "ncol": n,
                                     "note": "ECCKD_HOST: pageable host arrays staged over PCIe by every call (64 B/cell "
                                             "of intermediates out and back in); best of 3"}
+        out["fortran_device_resident"] = None
+        if side and args.dtype == "f64" and args.lut == "fsck" and args.fortran_sample > 0:
+            out["fortran_device_resident"] = fortran_device_resident(pkg, lw_file, min(args.fortran_sample, ncol), press_min, ng)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -40,6 +40,14 @@ extern "C" {
 
 #define ECCKD_HOST 0
 #define ECCKD_DEVICE 1
+/* ECCKD_MIXED: the big arrays live on the device, the small ones on the host -- the calling convention of a
+ * host model (Fortran, say) that keeps optical_props / sources in HBM between gas_optics and rte_* but holds
+ * its atmosphere and wants its fluxes in host memory.  Device pointers: tau, ssa, g, lay_source,
+ * lev_source_inc, lev_source_dec, sfc_source.  Host pointers, staged by the library: plev, tlay, tlev, tsfc,
+ * gas arrays, toa_src / toa_flux, mu0, sfc_emis, albedos, inc_flux, fluxes.  The call synchronises before it
+ * returns.  About 3.4 KB per column cross the bus instead of 34 KB (ECCKD_HOST).  Accepted by
+ * ecckd_gas_optics_lw / _sw, ecckd_rte_lw (and _shared_levels, _inc_flux) and ecckd_rte_sw. */
+#define ECCKD_MIXED 2
 
 /* concentration_dependence_code values, src/gas_optics_ecckd.f90:54-57 */
 #define ECCKD_NONE 0
@@ -210,6 +218,33 @@ int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int
                      const int *band2gpt, const float *sfc_emis, float *flux_up, float *flux_dn,
                      int memspace, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Fused longwave path (no counterpart call in the reference, whose block loop calls
+ * gas_optics and rte_lw back to back with nothing reading tau or the sources in between:
+ * ecckd_rfmip_lw.F90:120-135).  The three source arrays are pure functions of tlay / tlev / tsfc and the model's
+ * Planck table (src/gas_optics_ecckd.f90:407-424), so a host that only needs fluxes does not have to move them:
+ * gas optics writes tau only (8 B/cell) and the solver recomputes the sources while it reads tau (8 B/cell) --
+ * 16 instead of 64 B per (column, layer, g-point) between the two kernels.  Same arithmetic per cell (sources bit
+ * identical to ecckd_gas_optics_lw); fast arithmetic mode, fp64, 60 layers.  This path is bound by fp64 issue, not by
+ * HBM, and bench.py reports it apart from the API-boundary roofline ("fused_lw").
+ *   ecckd_gas_optics_lw_tau  gas_optical_depth (:323-376) alone: tau(ncol,nlay,ngpt)              ECCKD_DEVICE
+ *   ecckd_rte_lw_fused       rte_lw on tau + temperatures; sfc_emis(nband,ncol), inc_flux(ncol,ngpt) or NULL  ECCKD_DEVICE
+ *   ecckd_lw_fluxes          both, tau in library-owned stream-ordered scratch      ECCKD_DEVICE or ECCKD_HOST
+ * --------------------------------------------------------------------------------------- */
+int ecckd_gas_optics_lw_tau(const ecckd_model_t *model, int ncol, int nlay, const double *plev, const double *tlay,
+                            int ngas, const char *gas_names, const double *const *vmr,
+                            const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                            const double *vmr_scalar, double *tau, int memspace, void *stream);
+int ecckd_rte_lw_fused(const ecckd_model_t *model, int ncol, int nlay, int top_at_1, int n_gauss_angles,
+                       const double *tau, const double *tlay, const double *tlev, const double *tsfc,
+                       const double *sfc_emis, const double *inc_flux, double *flux_up, double *flux_dn,
+                       int memspace, void *stream);
+int ecckd_lw_fluxes(const ecckd_model_t *model, int ncol, int nlay, const double *plev, const double *tlay,
+                    const double *tsfc, const double *tlev, int ngas, const char *gas_names,
+                    const double *const *vmr, const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                    const double *vmr_scalar, int top_at_1, int n_gauss_angles, const double *sfc_emis,
+                    const double *inc_flux, double *flux_up, double *flux_dn, int memspace, void *stream);
+
 /* Two-stream + adding SW.  mu0(ncol), toa_flux(ncol,ngpt), sfc_alb_dir/dif(nband,ncol).
  * flux_dn includes the direct beam; flux_dir (ncol,nlay+1) may be NULL. */
 int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
@@ -234,6 +269,15 @@ int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, 
                         const double *sfc_alb_dif, double *bnd_flux_up, double *bnd_flux_dn,
                         double *bnd_flux_dir, double *flux_up, double *flux_dn, double *flux_dir,
                         int memspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Device memory for host languages without a HIP binding of their own (the Fortran shim's device-resident
+ * twins of ty_optical_props / ty_source_func_lw own their buffers through these).  to_device: 1 = host to
+ * device, 0 = device to host; synchronous.
+ * --------------------------------------------------------------------------------------- */
+int ecckd_device_malloc(int device, size_t bytes, void **ptr);
+int ecckd_device_free(int device, void *ptr);
+int ecckd_device_memcpy(int device, void *dst, const void *src, size_t bytes, int to_device);
 
 /* ---------------------------------------------------------------------------------------
  * Launch plan of a gas_optics call (no counterpart in the reference; works on host-only models,
@@ -278,6 +322,10 @@ int ecckd_get_arithmetic(void);
  *   "sw_k_floor"             k = sqrt(max((gamma1-gamma2)(gamma1+gamma2), sw_k_floor)), default 1e-12
  *   "sw_dir_clamp"           1: Rdir = max(0,min(Rdir,1-Tnoscat)), Tdir = max(0,min(Tdir,1-Tnoscat-Rdir))
  *                            (v1.6+); 0: no clamp (default)
+ * Implementation choices through the same call (results agree to ~1e-16 relative; bench.py prints them too):
+ *   "lw_solver"              fp64, 60 layers: 0 register-resident solver (one wave per SIMD), 1 layer-split solver
+ *                            (waves of a block share a tile and take 10-15 layers each; three waves per SIMD)
+ *   "lw_split_seg"           layers per wave of the layer-split solver: 10 (default), 12 or 15
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_solver_option(const char *name, double value);
 int ecckd_get_solver_option(const char *name, double *value);

@@ -33,7 +33,8 @@ LIB_PATH = os.environ.get("ECCKD_LIB", os.path.join(_HERE, "librte_ecckd_hip.so"
 HOST, DEVICE = 0, 1
 NAME_LEN = 32
 
-_SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_sw.hip",
+_SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_lw_split.hip",
+            "kernels_rte_sw.hip",
             "capi.cpp", "nc_capi.cpp", "model.cpp", "cdf1.cpp"]
 _HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h"),
             os.path.join("..", "..", "include", "ecckd_nc.h")]
@@ -79,7 +80,7 @@ FORTRAN_BUILD = os.path.join(FORTRAN_DIR, "build")
 FORTRAN_DRIVER = os.path.join(FORTRAN_BUILD, "ecckd_driver")
 RFMIP_LW = os.path.join(FORTRAN_BUILD, "ecckd_rfmip_lw")
 RFMIP_SW = os.path.join(FORTRAN_BUILD, "ecckd_rfmip_sw")
-_FORTRAN_MODULES = ["mo_rte_min.F90", "gas_optics_ecckd.F90", "mo_rte_solvers.F90", "rfmip_support.F90"]
+_FORTRAN_MODULES = ["mo_rte_min.F90", "mo_ecckd_device.F90", "gas_optics_ecckd.F90", "mo_rte_solvers.F90", "rfmip_support.F90"]
 _FORTRAN_PROGRAMS = [("ecckd_driver", "ecckd_driver.F90", []), ("ecckd_rfmip_lw", "ecckd_rfmip.F90", []),
                      ("ecckd_rfmip_sw", "ecckd_rfmip.F90", ["-DSHORTWAVE"])]
 
@@ -179,7 +180,8 @@ def get_arithmetic():
     return lib().ecckd_get_arithmetic()
 
 
-SOLVER_OPTIONS = ("lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor", "sw_dir_clamp")
+SOLVER_OPTIONS = ("lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor", "sw_dir_clamp", "lw_solver",
+                  "lw_split_seg")
 
 
 def set_solver_option(name, value):
@@ -202,6 +204,8 @@ def solver_options():
 
 
 def reset_solver_options():
+    """The version switches back to their (v1.5-era) defaults; the implementation choices (lw_solver, lw_split_seg)
+    are left alone."""
     for n, v in (("lw_tau_thresh", 0.0), ("lw_series_terms", 2), ("lw_inc_flux_isotropic", 0), ("sw_k_floor", 1e-12),
                  ("sw_dir_clamp", 0)):
         set_solver_option(n, v)
@@ -632,6 +636,50 @@ class GasOpticsEcckd:
                 P(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
                 P(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
         sources.levels_shared = rc == 0 and tlev is not None
+        return last_error() if rc else ""
+
+    def gas_optics_tau(self, plev, tlay, gas_desc, optical_props):
+        """``ecckd_gas_optics_lw_tau``: gas_optical_depth alone (tau only), device tensors."""
+        nlay, ncol = tlay.shape
+        ng = self.get_ngpt()
+        try:
+            space = _space_of([plev, tlay, optical_props.tau])
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+        except KeyError as e:
+            return str(e.args[0])
+        rc = lib().ecckd_gas_optics_lw_tau(self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"),
+                                           _ptr(tlay, (nlay, ncol), "tlay"), n, names, ptrs, cs, ls, sc,
+                                           _ptr(optical_props.tau, (ng, nlay, ncol), "tau"), space, _stream(space))
+        return last_error() if rc else ""
+
+    def rte_lw_fused(self, optical_props, top_at_1, tlay, tlev, tsfc, sfc_emis, fluxes, n_gauss_angles=1, inc_flux=None):
+        """``ecckd_rte_lw_fused``: rte_lw that recomputes the Planck sources from the temperatures (device tensors)."""
+        ng, nlay, ncol = optical_props.tau.shape
+        space = _space_of([optical_props.tau, tlay, tlev, tsfc, sfc_emis, inc_flux, fluxes.flux_up, fluxes.flux_dn])
+        rc = lib().ecckd_rte_lw_fused(self._need(), ncol, nlay, int(bool(top_at_1)), int(n_gauss_angles),
+                                      _ptr(optical_props.tau), _ptr(tlay, (nlay, ncol), "tlay"),
+                                      _ptr(tlev, (nlay + 1, ncol), "tlev"), _ptr(tsfc, (ncol,), "tsfc"),
+                                      _ptr(sfc_emis, (ncol, self.get_nband()), "sfc_emis"),
+                                      _ptr(inc_flux, (ng, ncol), "inc_flux"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+                                      _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"), space, _stream(space))
+        return last_error() if rc else ""
+
+    def lw_fluxes(self, plev, tlay, tsfc, tlev, gas_desc, top_at_1, sfc_emis, fluxes, n_gauss_angles=1, inc_flux=None):
+        """``ecckd_lw_fluxes``: gas optics + rte_lw in one call for hosts that only need broadband fluxes (tau in
+        library-owned scratch, sources recomputed in the solver); numpy or device tensors."""
+        nlay, ncol = tlay.shape
+        ng = self.get_ngpt()
+        try:
+            space = _space_of([plev, tlay, tsfc, tlev, sfc_emis, inc_flux, fluxes.flux_up, fluxes.flux_dn])
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+        except KeyError as e:
+            return str(e.args[0])
+        rc = lib().ecckd_lw_fluxes(self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"),
+                                   _ptr(tlay, (nlay, ncol), "tlay"), _ptr(tsfc, (ncol,), "tsfc"),
+                                   _ptr(tlev, (nlay + 1, ncol), "tlev"), n, names, ptrs, cs, ls, sc, int(bool(top_at_1)),
+                                   int(n_gauss_angles), _ptr(sfc_emis, (ncol, self.get_nband()), "sfc_emis"),
+                                   _ptr(inc_flux, (ng, ncol), "inc_flux"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+                                   _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"), space, _stream(space))
         return last_error() if rc else ""
 
     def gas_optics_ext(self, play, plev, tlay, gas_desc, optical_props, toa_src, col_dry=None):

@@ -128,6 +128,9 @@ struct F32Scope {
 // 1 = reference order (kernels_tau.hip + kernels_planck.hip, bit-faithful expression order).
 std::atomic<int> g_arith{0};
 
+#ifndef ECCKD_LW_DEFAULT_SOLVER
+#define ECCKD_LW_DEFAULT_SOLVER 0
+#endif
 // Version switches of the (un-pinned) RTE-RRTMGP solvers, ecckd_set_solver_option.  Process-wide, read once
 // per call; the defaults are the v1.5-era forms the oracle restates.
 struct SolverOptions {
@@ -136,6 +139,9 @@ struct SolverOptions {
   std::atomic<int> lw_inc_flux_isotropic{0};
   std::atomic<double> sw_k_floor{1.e-12};
   std::atomic<int> sw_dir_clamp{0};
+  // implementation choices (same results to ~1e-16 relative): which fp64 / 60-layer longwave solver runs
+  std::atomic<int> lw_solver{ECCKD_LW_DEFAULT_SOLVER};   // 0 register-resident (kernels_rte_lw.hip), 1 layer-split
+  std::atomic<int> lw_split_seg{10};
 };
 SolverOptions g_opt;
 
@@ -398,6 +404,36 @@ const char *ecckd_build_info(void) {
   return "rte-ecckd hot path for MI355X: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, fp64";
 }
 
+// ------------------------------- device memory for hosts without a HIP binding ---------------------
+
+int ecckd_device_malloc(int device, size_t bytes, void **ptr) {
+  if (!ptr) return fail("ecckd_device_malloc: null output");
+  *ptr = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail("ecckd: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail("ecckd_device_malloc: bad device ordinal");
+  HIPCHK(hipSetDevice(device));
+  if (bytes == 0) return 0;
+  HIPCHK(hipMalloc(ptr, bytes));
+  return 0;
+}
+
+int ecckd_device_free(int device, void *ptr) {
+  if (!ptr) return 0;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipFree(ptr));
+  return 0;
+}
+
+int ecckd_device_memcpy(int device, void *dst, const void *src, size_t bytes, int to_device) {
+  if (bytes == 0) return 0;
+  if (!dst || !src) return fail("ecckd_device_memcpy: null pointer");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // ------------------------------- kernel timing hooks -------------------------------------
 
 int ecckd_set_arithmetic(int mode) {
@@ -421,8 +457,14 @@ int ecckd_set_solver_option(const char *name, double value) {
     if (!(value > 0.)) return fail("ecckd_set_solver_option: sw_k_floor must be > 0");
     g_opt.sw_k_floor.store(value);
   } else if (n == "sw_dir_clamp") g_opt.sw_dir_clamp.store(value != 0. ? 1 : 0);
-  else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
-                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp)");
+  else if (n == "lw_solver") {
+    if (value != 0. && value != 1.) return fail("ecckd_set_solver_option: lw_solver must be 0 (register-resident) or 1 (layer-split)");
+    g_opt.lw_solver.store((int)value);
+  } else if (n == "lw_split_seg") {
+    if (value != 10. && value != 12. && value != 15.) return fail("ecckd_set_solver_option: lw_split_seg must be 10, 12 or 15");
+    g_opt.lw_split_seg.store((int)value);
+  } else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg)");
   return 0;
 }
 
@@ -434,6 +476,8 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "lw_inc_flux_isotropic") *value = g_opt.lw_inc_flux_isotropic.load();
   else if (n == "sw_k_floor") *value = g_opt.sw_k_floor.load();
   else if (n == "sw_dir_clamp") *value = g_opt.sw_dir_clamp.load();
+  else if (n == "lw_solver") *value = g_opt.lw_solver.load();
+  else if (n == "lw_split_seg") *value = g_opt.lw_split_seg.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -787,14 +831,19 @@ int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double
       return 1;
     return tlev ? 0 : fail("tlev is required for ecckd");   // :414-417
   }
-  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  if (memspace != ECCKD_HOST && memspace != ECCKD_MIXED) return fail("ecckd: bad memspace");
+  // ECCKD_MIXED: inputs are host arrays (staged here), the (ncol,nlay,ngpt) / (ncol,ngpt) outputs are the caller's
+  // device buffers: nothing but ~4 KB per column crosses the bus
+  const bool mixed = memspace == ECCKD_MIXED;
 
   ecckd_model *mm = const_cast<ecckd_model *>(m);
   std::lock_guard<std::mutex> lock(mm->mu);
   hipStream_t s = mm->host_stream;
   size_t need = align256(n2l * esz()) * 2 + align256(n2 * esz()) + align256((size_t)ncol * esz()) +
-                staged_gas_bytes(gd, ncol, nlay) + align256(n3 * esz()) * 4 + align256((size_t)ncol * m->ng * esz());
+                staged_gas_bytes(gd, ncol, nlay);
+  if (!mixed) need += align256(n3 * esz()) * 4 + align256((size_t)ncol * m->ng * esz());
   if (need > mm->arena_bytes) {
+    HIPCHK(hipStreamSynchronize(s));
     if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
     HIPCHK(hipMalloc(&mm->arena, need));
     mm->arena_bytes = need;
@@ -805,16 +854,21 @@ int ecckd_gas_optics_lw(const ecckd_model_t *m, int ncol, int nlay, const double
   if (tlev && h2d(d_tlev, tlev, n2l, s)) return 1;
   StagedGases sg;
   if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
-  double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
-  double *d_sfc = b.take((size_t)ncol * m->ng);
+  double *d_tau = tau, *d_lay = lay_source, *d_inc = lev_source_inc, *d_dec = lev_source_dec, *d_sfc = sfc_source;
+  if (!mixed) {
+    d_tau = b.take(n3); d_lay = b.take(n3); d_inc = b.take(n3); d_dec = b.take(n3);
+    d_sfc = b.take((size_t)ncol * m->ng);
+  }
   if (gas_optics_lw_dev(m, ncol, nlay, d_plev, d_tlay, d_tsfc, tlev ? d_tlev : nullptr, sg.gd, d_tau,
                         d_lay, d_inc, d_dec, d_sfc, s))
     return 1;
-  if (d2h(tau, d_tau, n3, s) || d2h(lay_source, d_lay, n3, s) ||
-      d2h(sfc_source, d_sfc, (size_t)ncol * m->ng, s))
-    return 1;
-  if (tlev && (d2h(lev_source_inc, d_inc, n3, s) || d2h(lev_source_dec, d_dec, n3, s))) return 1;
-  HIPCHK(hipStreamSynchronize(s));
+  if (!mixed) {
+    if (d2h(tau, d_tau, n3, s) || d2h(lay_source, d_lay, n3, s) ||
+        d2h(sfc_source, d_sfc, (size_t)ncol * m->ng, s))
+      return 1;
+    if (tlev && (d2h(lev_source_inc, d_inc, n3, s) || d2h(lev_source_dec, d_dec, n3, s))) return 1;
+  }
+  HIPCHK(hipStreamSynchronize(s));   // (mixed too: the solver call that follows runs on another stream)
   return tlev ? 0 : fail("tlev is required for ecckd");
 }
 
@@ -866,14 +920,17 @@ int ecckd_gas_optics_sw(const ecckd_model_t *m, int ncol, int nlay, const double
       return 1;
     return two_stream ? 0 : fail(kNot2str);
   }
-  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  if (memspace != ECCKD_HOST && memspace != ECCKD_MIXED) return fail("ecckd: bad memspace");
+  const bool mixed = memspace == ECCKD_MIXED;   // tau, ssa, g: caller's device buffers; toa_src and the inputs: host
 
   ecckd_model *mm = const_cast<ecckd_model *>(m);
   std::lock_guard<std::mutex> lock(mm->mu);
   hipStream_t s = mm->host_stream;
   size_t need = align256(n2l * esz()) + align256(n2 * esz()) + staged_gas_bytes(gd, ncol, nlay) +
-                align256(n3 * esz()) * 3 + align256((size_t)ncol * m->ng * esz());
+                align256((size_t)ncol * m->ng * esz());
+  if (!mixed) need += align256(n3 * esz()) * 3;
   if (need > mm->arena_bytes) {
+    HIPCHK(hipStreamSynchronize(s));
     if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
     HIPCHK(hipMalloc(&mm->arena, need));
     mm->arena_bytes = need;
@@ -883,14 +940,17 @@ int ecckd_gas_optics_sw(const ecckd_model_t *m, int ncol, int nlay, const double
   if (h2d(d_plev, plev, n2l, s) || h2d(d_tlay, tlay, n2, s)) return 1;
   StagedGases sg;
   if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
-  double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3);
   double *d_toa = b.take((size_t)ncol * m->ng);
+  double *d_tau = tau, *d_ssa = ssa, *d_g = g;
+  if (!mixed) { d_tau = b.take(n3); d_ssa = b.take(n3); d_g = b.take(n3); }
   if (gas_optics_sw_dev(m, ncol, nlay, d_plev, d_tlay, sg.gd, d_tau, two_stream ? d_ssa : nullptr,
                         two_stream ? d_g : nullptr, d_toa, s))
     return 1;
-  if (d2h(tau, d_tau, n3, s)) return 1;
-  if (two_stream && (d2h(ssa, d_ssa, n3, s) || d2h(g, d_g, n3, s) || d2h(toa_src, d_toa, (size_t)ncol * m->ng, s)))
-    return 1;
+  if (!mixed) {
+    if (d2h(tau, d_tau, n3, s)) return 1;
+    if (two_stream && (d2h(ssa, d_ssa, n3, s) || d2h(g, d_g, n3, s))) return 1;
+  }
+  if (two_stream && d2h(toa_src, d_toa, (size_t)ncol * m->ng, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
   return two_stream ? 0 : fail(kNot2str);
 }
@@ -940,6 +1000,8 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
     a.tau_thresh = t > 0. ? t : (g_f32 ? std::sqrt(1.1920928955078125e-07) : std::sqrt(2.220446049250313e-16));   // sqrt(epsilon(1._wp))
     a.series3 = g_opt.lw_series_terms.load() == 3;
     a.inc_isotropic = g_opt.lw_inc_flux_isotropic.load();
+    a.use_split = g_opt.lw_solver.load();
+    a.split_seg = g_opt.lw_split_seg.load();
   }
   for (int k = 0; k < n_gauss_angles; ++k) {
     a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
@@ -964,24 +1026,34 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
     }
     return 0;
   }
-  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  if (memspace != ECCKD_HOST && memspace != ECCKD_MIXED) return fail("ecckd: bad memspace");
+  // ECCKD_MIXED: tau, the three source arrays and sfc_source are device buffers (what gas_optics left there);
+  // sfc_emis / inc_flux come from the host and the fluxes go back to it
+  const bool mixed = memspace == ECCKD_MIXED;
   Arena &ar = g_solver_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
-  const size_t need = align256(n3 * esz()) * 4 + align256((size_t)ncol * ngpt * esz()) * 2 +
-                      align256((size_t)ncol * nband * esz()) + align256(n2l * esz()) * 2;
+  const size_t need = (mixed ? 0 : align256(n3 * esz()) * 4 + align256((size_t)ncol * ngpt * esz())) +
+                      align256((size_t)ncol * ngpt * esz()) + align256((size_t)ncol * nband * esz()) +
+                      align256(n2l * esz()) * 2;
   if (ar.ensure(need)) return 1;
   Bump b(ar.p);
-  double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
-  double *d_sfc = b.take((size_t)ncol * ngpt), *d_emis = b.take((size_t)ncol * nband);
-  double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_incf = b.take((size_t)ncol * ngpt);
   hipStream_t s = nullptr;
-  if (h2d(d_tau, tau, n3, s) || h2d(d_lay, lay_source, n3, s) || h2d(d_inc, lev_source_inc, n3, s) ||
-      h2d(d_dec, lev_source_dec, n3, s) || h2d(d_sfc, sfc_source, (size_t)ncol * ngpt, s) ||
-      h2d(d_emis, sfc_emis, (size_t)ncol * nband, s))
-    return 1;
+  if (mixed) {
+    a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc; a.lev_source_dec = lev_source_dec;
+    a.sfc_source = sfc_source;
+  } else {
+    double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
+    double *d_sfc = b.take((size_t)ncol * ngpt);
+    if (h2d(d_tau, tau, n3, s) || h2d(d_lay, lay_source, n3, s) || h2d(d_inc, lev_source_inc, n3, s) ||
+        h2d(d_dec, lev_source_dec, n3, s) || h2d(d_sfc, sfc_source, (size_t)ncol * ngpt, s))
+      return 1;
+    a.tau = d_tau; a.lay_source = d_lay; a.lev_source_inc = d_inc; a.lev_source_dec = d_dec; a.sfc_source = d_sfc;
+  }
+  double *d_emis = b.take((size_t)ncol * nband), *d_up = b.take(n2l), *d_dn = b.take(n2l);
+  double *d_incf = b.take((size_t)ncol * ngpt);
+  if (h2d(d_emis, sfc_emis, (size_t)ncol * nband, s)) return 1;
   if (g_inc_flux && h2d(d_incf, g_inc_flux, (size_t)ncol * ngpt, s)) return 1;
-  a.tau = d_tau; a.lay_source = d_lay; a.lev_source_inc = d_inc; a.lev_source_dec = d_dec;
-  a.sfc_source = d_sfc; a.sfc_emis = d_emis; a.flux_up = d_up; a.flux_dn = d_dn;
+  a.sfc_emis = d_emis; a.flux_up = d_up; a.flux_dn = d_dn;
   a.inc_flux = g_inc_flux ? d_incf : nullptr;
   HIPCHK(ecckd::launch_rte_lw(a, s));
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
@@ -1062,26 +1134,147 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
     }
     return 0;
   }
-  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  if (memspace != ECCKD_HOST && memspace != ECCKD_MIXED) return fail("ecckd: bad memspace");
+  const bool mixed = memspace == ECCKD_MIXED;   // tau, ssa, g: device buffers; everything else host
   Arena &ar = g_solver_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
-  const size_t need = align256(n3 * esz()) * 3 + align256((size_t)ncol * esz()) + align256((size_t)ncol * ngpt * esz()) +
-                      align256((size_t)ncol * nband * esz()) * 2 + align256(n2l * esz()) * 3;
+  const size_t need = (mixed ? 0 : align256(n3 * esz()) * 3) + align256((size_t)ncol * esz()) +
+                      align256((size_t)ncol * ngpt * esz()) + align256((size_t)ncol * nband * esz()) * 2 +
+                      align256(n2l * esz()) * 3;
   if (ar.ensure(need)) return 1;
   Bump b(ar.p);
-  double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3), *d_mu0 = b.take(ncol);
+  hipStream_t s = nullptr;
+  if (mixed) {
+    a.tau = tau; a.ssa = ssa; a.g = g;
+  } else {
+    double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3);
+    if (h2d(d_tau, tau, n3, s) || h2d(d_ssa, ssa, n3, s) || h2d(d_g, g, n3, s)) return 1;
+    a.tau = d_tau; a.ssa = d_ssa; a.g = d_g;
+  }
+  double *d_mu0 = b.take(ncol);
   double *d_toa = b.take((size_t)ncol * ngpt), *d_ad = b.take((size_t)ncol * nband), *d_af = b.take((size_t)ncol * nband);
   double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_dir = b.take(n2l);
-  hipStream_t s = nullptr;
-  if (h2d(d_tau, tau, n3, s) || h2d(d_ssa, ssa, n3, s) || h2d(d_g, g, n3, s) || h2d(d_mu0, mu0, ncol, s) ||
-      h2d(d_toa, toa_flux, (size_t)ncol * ngpt, s) || h2d(d_ad, sfc_alb_dir, (size_t)ncol * nband, s) ||
-      h2d(d_af, sfc_alb_dif, (size_t)ncol * nband, s))
+  if (h2d(d_mu0, mu0, ncol, s) || h2d(d_toa, toa_flux, (size_t)ncol * ngpt, s) ||
+      h2d(d_ad, sfc_alb_dir, (size_t)ncol * nband, s) || h2d(d_af, sfc_alb_dif, (size_t)ncol * nband, s))
     return 1;
-  a.tau = d_tau; a.ssa = d_ssa; a.g = d_g; a.mu0 = d_mu0; a.toa = d_toa; a.alb_dir = d_ad; a.alb_dif = d_af;
+  a.mu0 = d_mu0; a.toa = d_toa; a.alb_dir = d_ad; a.alb_dif = d_af;
   a.flux_up = d_up; a.flux_dn = d_dn; a.flux_dir = flux_dir ? d_dir : nullptr;
   HIPCHK(ecckd::launch_rte_sw(a, s));
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   if (flux_dir && d2h(flux_dir, d_dir, n2l, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- fused longwave: tau-only gas optics + solver that recomputes the Planck sources ----
+
+int ecckd_gas_optics_lw_tau(const ecckd_model_t *m, int ncol, int nlay, const double *plev, const double *tlay, int ngas,
+                            const char *gas_names, const double *const *vmr, const long long *vmr_col_stride,
+                            const long long *vmr_lay_stride, const double *vmr_scalar, double *tau, int memspace,
+                            void *stream) {
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
+  if (memspace != ECCKD_DEVICE) return fail("ecckd_gas_optics_lw_tau: device arrays only (ECCKD_DEVICE); ecckd_lw_fluxes takes host arrays");
+  if (!plev || !tlay || !tau || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_lw_tau: null argument");
+  HIPCHK(hipSetDevice(m->device));
+  if (ncol == 0) return 0;
+  const GasDesc gd{ngas, gas_names, vmr, vmr_col_stride, vmr_lay_stride, vmr_scalar};
+  return gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, tau, false, nullptr, nullptr, nullptr, nullptr,
+                               static_cast<hipStream_t>(stream));
+}
+
+static int rte_lw_fused_dev(const ecckd_model *m, int ncol, int nlay, int top_at_1, int n_gauss_angles, const double *tau,
+                            const double *tlay, const double *tlev, const double *tsfc, const double *sfc_emis,
+                            const double *inc_flux, double *flux_up, double *flux_dn, hipStream_t stream) {
+  if (nlay != 60) return fail("ecckd: the fused longwave solver is implemented for 60 layers (use gas_optics + rte_lw)");
+  ecckd::RteLwArgs a{};
+  if (fill_band_map(m->ng, m->nband, m->band2gpt.data(), a.gpt2band)) return 1;
+  a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
+  a.nband = m->nband;
+  {
+    const double t = g_opt.lw_tau_thresh.load();
+    a.tau_thresh = t > 0. ? t : std::sqrt(2.220446049250313e-16);
+    a.series3 = g_opt.lw_series_terms.load() == 3;
+    a.inc_isotropic = g_opt.lw_inc_flux_isotropic.load();
+    a.use_split = 1;
+    a.split_seg = g_opt.lw_split_seg.load();
+  }
+  for (int k = 0; k < n_gauss_angles; ++k) {
+    a.Ds[k] = kGaussDs[n_gauss_angles - 1][k];
+    a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
+  }
+  a.tau = tau; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux; a.flux_up = flux_up; a.flux_dn = flux_dn;
+  ProfScope prof("rte_lw_fused", stream);
+  HIPCHK(ecckd::launch_rte_lw_planck(a, m->dbuf + m->off_planck, m->ntp, m->temperature_planck[0],
+                                     m->temperature_planck[1] - m->temperature_planck[0], tlay, tlev, tsfc, stream));
+  return 0;
+}
+
+int ecckd_rte_lw_fused(const ecckd_model_t *m, int ncol, int nlay, int top_at_1, int n_gauss_angles, const double *tau,
+                       const double *tlay, const double *tlev, const double *tsfc, const double *sfc_emis,
+                       const double *inc_flux, double *flux_up, double *flux_dn, int memspace, void *stream) {
+  if (check_model(m) || check_dims(ncol, nlay)) return 1;
+  if (!m->has_planck) return fail("ecckd_rte_lw_fused: model has no Planck table (shortwave model?)");
+  if (memspace != ECCKD_DEVICE) return fail("ecckd_rte_lw_fused: device arrays only (ECCKD_DEVICE); ecckd_lw_fluxes takes host arrays");
+  if (n_gauss_angles < 1 || n_gauss_angles > 4) return fail("rte_lw: have to ask for at least one quadrature point and no more than 4");
+  if (!tau || !tlay || !tsfc || !sfc_emis || !flux_up || !flux_dn) return fail("ecckd_rte_lw_fused: null argument");
+  if (!tlev) return fail("tlev is required for ecckd");
+  HIPCHK(hipSetDevice(m->device));
+  if (ncol == 0) return 0;
+  return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,
+                          flux_dn, static_cast<hipStream_t>(stream));
+}
+
+int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *plev, const double *tlay, const double *tsfc,
+                    const double *tlev, int ngas, const char *gas_names, const double *const *vmr,
+                    const long long *vmr_col_stride, const long long *vmr_lay_stride, const double *vmr_scalar, int top_at_1,
+                    int n_gauss_angles, const double *sfc_emis, const double *inc_flux, double *flux_up, double *flux_dn,
+                    int memspace, void *stream) {
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
+  if (!m->has_planck) return fail("ecckd_lw_fluxes: model has no Planck table (shortwave model?)");
+  if (n_gauss_angles < 1 || n_gauss_angles > 4) return fail("rte_lw: have to ask for at least one quadrature point and no more than 4");
+  if (!plev || !tlay || !tsfc || !sfc_emis || !flux_up || !flux_dn || (ngas > 0 && !gas_names)) return fail("ecckd_lw_fluxes: null argument");
+  if (!tlev) return fail("tlev is required for ecckd");
+  if (g_arith.load() != 0) return fail("ecckd_lw_fluxes: needs the fast arithmetic mode (ecckd_set_arithmetic(0))");
+  HIPCHK(hipSetDevice(m->device));
+  if (ncol == 0) return 0;
+  const GasDesc gd{ngas, gas_names, vmr, vmr_col_stride, vmr_lay_stride, vmr_scalar};
+  const size_t n2 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1), n3 = n2 * m->ng;
+  if (memspace == ECCKD_DEVICE) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void *tau_p = nullptr;   // tau lives in the stream's scratch block between the two kernels
+    if (stream_scratch(m->device, st, n3 * sizeof(double), &tau_p)) return 1;
+    double *d_tau = static_cast<double *>(tau_p);
+    if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, d_tau, false, nullptr, nullptr, nullptr, nullptr, st)) return 1;
+    return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, d_tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,
+                            flux_dn, st);
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  ecckd_model *mm = const_cast<ecckd_model *>(m);
+  std::lock_guard<std::mutex> lock(mm->mu);
+  hipStream_t s = mm->host_stream;
+  const size_t need = align256(n2l * 8) * 4 + align256(n2 * 8) + align256((size_t)ncol * 8) + staged_gas_bytes(gd, ncol, nlay) +
+                      align256((size_t)ncol * m->nband * 8) + align256((size_t)ncol * m->ng * 8) + align256(n3 * 8);
+  if (need > mm->arena_bytes) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
+    HIPCHK(hipMalloc(&mm->arena, need));
+    mm->arena_bytes = need;
+  }
+  Bump b(mm->arena);
+  double *d_plev = b.take(n2l), *d_tlev = b.take(n2l), *d_tlay = b.take(n2), *d_tsfc = b.take(ncol);
+  double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_emis = b.take((size_t)ncol * m->nband), *d_incf = b.take((size_t)ncol * m->ng);
+  if (h2d(d_plev, plev, n2l, s) || h2d(d_tlay, tlay, n2, s) || h2d(d_tsfc, tsfc, ncol, s) || h2d(d_tlev, tlev, n2l, s) ||
+      h2d(d_emis, sfc_emis, (size_t)ncol * m->nband, s))
+    return 1;
+  if (inc_flux && h2d(d_incf, inc_flux, (size_t)ncol * m->ng, s)) return 1;
+  StagedGases sg;
+  if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
+  double *d_tau = b.take(n3);
+  if (gas_optical_depth_dev(m, ncol, nlay, d_plev, d_tlay, sg.gd, d_tau, false, nullptr, nullptr, nullptr, nullptr, s)) return 1;
+  if (rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, d_tau, d_tlay, d_tlev, d_tsfc, d_emis, inc_flux ? d_incf : nullptr,
+                       d_up, d_dn, s))
+    return 1;
+  if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
   return 0;
 }

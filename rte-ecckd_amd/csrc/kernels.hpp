@@ -105,6 +105,9 @@ struct RteLwArgs {
   double tau_thresh;           // lw_source_noscat: series below this optical depth (sqrt(epsilon) of the precision)
   int series3;                 // 0: tau*(0.5 - tau/3) (v1.5), 1: tau*(0.5 + tau*(-1/3 + tau/8))
   int inc_isotropic;           // 0: I_dn(top) = inc_flux/(2 pi w_k) per angle, 1: inc_flux/pi
+  // implementation choice for fp64 / 60 layers (ecckd_set_solver_option "lw_solver", "lw_split_seg")
+  int use_split;               // 1: layer-split solver (kernels_rte_lw_split.hip), 0: register-resident solver
+  int split_seg;               // layers per wave of the layer-split solver: 10, 12 or 15
 };
 
 struct RteSwArgs {
@@ -144,6 +147,13 @@ hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src
 // out(i) = sum_b planes(i, b): broadband from per-band fluxes
 hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double *out, int f32, hipStream_t s);
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);
+// layer-split form (kernels_rte_lw_split.hip): fp64, 60 layers
+bool rte_lw_split_applies(const RteLwArgs &a);
+hipError_t launch_rte_lw_split(const RteLwArgs &a, hipStream_t s);
+// ... with the Planck sources recomputed in the solver from tlay(ncol,nlay), tlev(ncol,nlay+1), tsfc(ncol) and the
+// model's table planck(ng,ntp) (a.lay_source / lev_source_* / sfc_source are not read)
+hipError_t launch_rte_lw_planck(const RteLwArgs &a, const double *planck, int ntp, double t0, double dt, const double *tlay,
+                                const double *tlev, const double *tsfc, hipStream_t s);
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s);
 
 }  // namespace ecckd

@@ -34,6 +34,8 @@
 //   (src/gas_optics_ecckd.f90:419-424: both are slices of one buffer).  The source at the far edge
 //   of a layer is then the near-edge source of the next one: it is carried in a register and only
 //   the first layer reads the second array (24 instead of 32 B/cell).  Same arithmetic, same bits.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace ecckd {
@@ -333,6 +335,7 @@ size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
 
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
+  if (a.use_split && rte_lw_split_applies(a)) return launch_rte_lw_split(a, s);
   if (a.shared_levels && !a.f32) return launch_real<double, true>(a, s);   // (no single-precision entry point sets it)
   return a.f32 ? launch_real<float, false>(a, s) : launch_real<double, false>(a, s);
 }

@@ -2,7 +2,13 @@
 ! example/rfmip-rad-irf/ecckd_rfmip_lw.F90:107-136 and ecckd_rfmip_sw.F90:112-162: load the ecCKD
 ! file, then per column block gas_optics() followed by rte_lw()/rte_sw(), fluxes out.
 !
-!   ecckd_driver lw|sw  <ecckd_file.nc>  <input.bin>  <output.bin>  [block_size] [n_quad_angles]
+!   ecckd_driver lw|sw  <ecckd_file.nc>  <input.bin>  <output.bin>  [block_size] [n_quad_angles] [device_resident 0|1] [repeats] [byband 0|1]
+!
+! device_resident = 1: optical_props / source are the device twins of mo_ecckd_device (tau and the sources stay in
+! HBM between gas_optics and the solver; ECCKD_MIXED memory space of the C ABI).
+! repeats: the block loop is run that many times and the best wall time is printed ("loop_seconds", bench.py reads it).
+! byband = 1: fluxes go through ty_fluxes_byband (per-band arrays; their sum over bands must reproduce the broadband
+! fluxes, which are what output.bin holds either way).
 !
 ! input.bin (little-endian, written by tests/test_fortran_shim.py): int32 ncol, nlay, ngas; per gas
 ! a 32-char name; then float64 arrays in Fortran order: plev(ncol,nlay+1), tlev(ncol,nlay+1),
@@ -13,8 +19,10 @@ program ecckd_driver
   use, intrinsic :: iso_fortran_env, only: error_unit, int32
   use gas_optics_ecckd, only: ty_gas_optics_ecckd
   use mo_fluxes, only: ty_fluxes_broadband
+  use mo_fluxes_byband, only: ty_fluxes_byband
   use mo_gas_concentrations, only: ty_gas_concs
   use mo_optical_props, only: ty_optical_props_1scl, ty_optical_props_2str
+  use mo_ecckd_device, only: ty_optical_props_1scl_dev, ty_optical_props_2str_dev, ty_source_func_lw_dev
   use mo_rte_kind, only: wp
   use mo_rte_lw, only: rte_lw
   use mo_rte_sw, only: rte_sw
@@ -22,7 +30,11 @@ program ecckd_driver
   implicit none
   character(len=512) :: mode, ecckd_path, in_path, out_path, arg
   integer(int32) :: ncol, nlay, ngas
-  integer :: block_size, n_quad_angles, nblocks, b, c0, c1, nc, i, ibnd, nbnd, u
+  integer :: block_size, n_quad_angles, nblocks, b, c0, c1, nc, i, ibnd, nbnd, u, dev_flag, repeats, rep, byband
+  integer(kind=8) :: t0, t1, rate
+  integer :: nc_alloc = -1
+  real(wp) :: best, secs
+  real(wp), dimension(:,:,:), allocatable, target :: bnd_up, bnd_dn
   logical :: top_at_1, lw
   character(len=32), dimension(:), allocatable :: gas_names
   real(wp), dimension(:,:), allocatable :: plev, tlev, tlay, play
@@ -31,11 +43,13 @@ program ecckd_driver
   real(wp), dimension(:,:), allocatable, target :: flux_up, flux_dn
   real(wp), dimension(:,:), allocatable :: sfc_spec, sfc_spec2, toa
   type(ty_gas_optics_ecckd) :: ecckd
-  type(ty_gas_concs) :: gas_concs
-  type(ty_source_func_lw) :: source
-  type(ty_optical_props_1scl) :: op1
-  type(ty_optical_props_2str) :: op2
-  type(ty_fluxes_broadband) :: fluxes
+  type(ty_gas_concs), dimension(:), allocatable :: gas_concs   ! one per block, filled before the loop (mo_rfmip_io.F90:177-263)
+  class(ty_source_func_lw), allocatable :: source
+  class(ty_optical_props_1scl), allocatable :: op1
+  class(ty_optical_props_2str), allocatable :: op2
+  type(ty_fluxes_broadband), target :: fluxes_bb
+  type(ty_fluxes_byband), target :: fluxes_band
+  class(ty_fluxes_broadband), pointer :: fluxes
 
   if (command_argument_count() < 4) then
     write(error_unit, *) "usage: ecckd_driver lw|sw ecckd_file input.bin output.bin [block_size] [n_quad_angles]"
@@ -55,7 +69,36 @@ program ecckd_driver
     call get_command_argument(6, arg)
     read(arg, *) n_quad_angles
   end if
+  dev_flag = 0
+  if (command_argument_count() >= 7) then
+    call get_command_argument(7, arg)
+    read(arg, *) dev_flag
+  end if
+  repeats = 1
+  if (command_argument_count() >= 8) then
+    call get_command_argument(8, arg)
+    read(arg, *) repeats
+  end if
+  byband = 0
+  if (command_argument_count() >= 9) then
+    call get_command_argument(9, arg)
+    read(arg, *) byband
+  end if
+  if (byband /= 0) then
+    fluxes => fluxes_band
+  else
+    fluxes => fluxes_bb
+  end if
   lw = trim(mode) == "lw"
+  if (dev_flag /= 0) then
+    allocate(ty_source_func_lw_dev :: source)
+    allocate(ty_optical_props_1scl_dev :: op1)
+    allocate(ty_optical_props_2str_dev :: op2)
+  else
+    allocate(ty_source_func_lw :: source)
+    allocate(ty_optical_props_1scl :: op1)
+    allocate(ty_optical_props_2str :: op2)
+  end if
 
   open(newunit=u, file=trim(in_path), access="stream", form="unformatted", status="old")
   read(u) ncol, nlay, ngas
@@ -81,16 +124,36 @@ program ecckd_driver
   allocate(flux_up(ncol, nlay + 1), flux_dn(ncol, nlay + 1))
   nblocks = (ncol + block_size - 1) / block_size
 
+  ! gas concentrations per block, as read_and_block_gases_ty prepares them before the reference's loop
+  ! (mo_rfmip_io.F90:177-263); a field that is uniform goes in as a scalar, as RFMIP's well-mixed gases do
+  allocate(gas_concs(nblocks))
+  do b = 1, nblocks
+    c0 = (b - 1) * block_size + 1
+    c1 = min(ncol, b * block_size)
+    call stop_on_err(gas_concs(b)%init(gas_names))
+    do i = 1, ngas
+      if (all(vmr(c0:c1, :, i) == vmr(c0, 1, i))) then
+        call stop_on_err(gas_concs(b)%set_vmr(trim(gas_names(i)), vmr(c0, 1, i)))
+      else
+        call stop_on_err(gas_concs(b)%set_vmr(trim(gas_names(i)), vmr(c0:c1, :, i)))
+      end if
+    end do
+  end do
+  best = huge(1._wp)
+  do rep = 1, max(1, repeats)
+  call system_clock(t0, rate)
   do b = 1, nblocks
     c0 = (b - 1) * block_size + 1
     c1 = min(ncol, b * block_size)
     nc = c1 - c0 + 1
-    call stop_on_err(gas_concs%init(gas_names))
-    do i = 1, ngas
-      call stop_on_err(gas_concs%set_vmr(trim(gas_names(i)), vmr(c0:c1, :, i)))
-    end do
     fluxes%flux_up => flux_up(c0:c1, :)
     fluxes%flux_dn => flux_dn(c0:c1, :)
+    if (byband /= 0) then
+      if (allocated(bnd_up)) deallocate(bnd_up, bnd_dn)
+      allocate(bnd_up(nc, nlay + 1, nbnd), bnd_dn(nc, nlay + 1, nbnd))
+      fluxes_band%bnd_flux_up => bnd_up
+      fluxes_band%bnd_flux_dn => bnd_dn
+    end if
     if (allocated(sfc_spec)) deallocate(sfc_spec)
     allocate(sfc_spec(nbnd, nc))
     do i = 1, nc                                             ! ecckd_rfmip_lw.F90:112-116
@@ -99,9 +162,12 @@ program ecckd_driver
       end do
     end do
     if (lw) then
-      call stop_on_err(source%alloc(nc, nlay, ecckd))
-      call stop_on_err(op1%alloc_1scl(nc, nlay, ecckd))
-      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), tsfc(c0:c1), gas_concs, &
+      if (nc /= nc_alloc) then                                 ! (the reference allocates once, before its loop: :102-103)
+        call stop_on_err(source%alloc(nc, nlay, ecckd))
+        call stop_on_err(op1%alloc_1scl(nc, nlay, ecckd))
+        nc_alloc = nc
+      end if
+      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), tsfc(c0:c1), gas_concs(b), &
                                         op1, source, tlev=tlev(c0:c1, :)))
       ! ecckd level sources hold one value per level (src/gas_optics_ecckd.f90:419-424): each level is read once
       call stop_on_err(rte_lw(op1, top_at_1, source, sfc_spec, fluxes, n_gauss_angles=n_quad_angles, &
@@ -113,11 +179,24 @@ program ecckd_driver
         sfc_spec(:, i) = bc2(c0 + i - 1)                     ! albedo, direct = diffuse (ecckd_rfmip_sw.F90:136-141)
         sfc_spec2(:, i) = bc2(c0 + i - 1)
       end do
-      call stop_on_err(op2%alloc_2str(nc, nlay, ecckd))
-      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), gas_concs, op2, toa))
+      if (nc /= nc_alloc) then
+        call stop_on_err(op2%alloc_2str(nc, nlay, ecckd))
+        nc_alloc = nc
+      end if
+      call stop_on_err(ecckd%gas_optics(play(c0:c1, :), plev(c0:c1, :), tlay(c0:c1, :), gas_concs(b), op2, toa))
       call stop_on_err(rte_sw(op2, top_at_1, bc1(c0:c1), toa, sfc_spec, sfc_spec2, fluxes))
     end if
+    if (byband /= 0) then
+      if (maxval(abs(sum(bnd_up, dim=3) - flux_up(c0:c1, :))) > 1.e-9_wp .or. &
+          maxval(abs(sum(bnd_dn, dim=3) - flux_dn(c0:c1, :))) > 1.e-9_wp) &
+        call stop_on_err("ecckd_driver: per-band fluxes do not add up to the broadband fluxes")
+    end if
   end do
+  call system_clock(t1)
+  secs = real(t1 - t0, wp) / real(rate, wp)
+  best = min(best, secs)
+  end do
+  write(error_unit, "(a,es12.5)") " ecckd_driver: loop_seconds ", best
 
   open(newunit=u, file=trim(out_path), access="stream", form="unformatted", status="replace")
   write(u) flux_up, flux_dn

@@ -1,8 +1,12 @@
 ! ecckd_rfmip.F90 -- RFMIP RAD-IRF drivers over the MI355X path; one source, two executables with the
 ! reference's names and command line (example/rfmip-rad-irf/Makefile:12-40, utils.f90:26-37):
 !
-!     ecckd_rfmip_lw rfmip_file ecckd_file [-f 1|2] [-p 1|2] [-b block] [-n nblocks]      (default build)
-!     ecckd_rfmip_sw rfmip_file ecckd_file [-f 1|2]          [-b block] [-n nblocks]      (-DSHORTWAVE)
+!     ecckd_rfmip_lw rfmip_file ecckd_file [-f 1|2] [-p 1|2] [-b block] [-n nblocks] [-d]   (default build)
+!     ecckd_rfmip_sw rfmip_file ecckd_file [-f 1|2]          [-b block] [-n nblocks] [-d]   (-DSHORTWAVE)
+!
+! -d: device-resident mode.  optical_props / source are the device twins of mo_ecckd_device: tau and the
+! sources stay in the GPU's memory between gas_optics and rte_lw / rte_sw, only the atmosphere goes in and the
+! fluxes come out (the C ABI's ECCKD_MIXED memory space).  Same calls, same fluxes bit for bit.
 !
 ! Same steps as ecckd_rfmip_lw.F90:38-140 / ecckd_rfmip_sw.F90:40-166: sizes, output names
 ! r{l,s}{u,d}_Efx_RTE-ecckd_rad-irf_r1i1p<p>f<f>_gn.nc, gas names by forcing index, blocked inputs,
@@ -23,9 +27,11 @@ program ecckd_rfmip
   use utils, only: determine_gas_names, parse_args
 #ifdef SHORTWAVE
   use mo_optical_props, only: ty_optical_props_2str
+  use mo_ecckd_device, only: ty_optical_props_2str_dev
   use mo_rte_sw, only: rte_sw
 #else
   use mo_optical_props, only: ty_optical_props_1scl
+  use mo_ecckd_device, only: ty_optical_props_1scl_dev, ty_source_func_lw_dev
   use mo_rte_lw, only: rte_lw
   use mo_source_functions, only: ty_source_func_lw
 #endif
@@ -36,7 +42,7 @@ program ecckd_rfmip
   character(len=32), dimension(6) :: kdist_names, rfmip_names
   integer :: ncol, nlay, nexp, nbnd, nblocks, ndo, block_size, max_blocks, forcing_index, physics_index
   integer :: b, i
-  logical :: top_at_1
+  logical :: top_at_1, device_resident
   real(wp), dimension(:,:,:), allocatable :: p_lay, p_lev, t_lay, t_lev
   real(wp), dimension(:,:,:), allocatable, target :: flux_up, flux_dn
   real(wp), dimension(:,:), allocatable :: bc_spec
@@ -49,15 +55,15 @@ program ecckd_rfmip
   real(wp), dimension(:), allocatable :: mu0, def_tsi
   logical, dimension(:,:), allocatable :: usecol
   integer :: ngpt
-  type(ty_optical_props_2str) :: optical_props
+  class(ty_optical_props_2str), allocatable :: optical_props
 #else
   integer :: n_quad_angles
   real(wp), dimension(:,:), allocatable :: sfc_emis, sfc_t
-  type(ty_optical_props_1scl) :: optical_props
-  type(ty_source_func_lw) :: source
+  class(ty_optical_props_1scl), allocatable :: optical_props
+  class(ty_source_func_lw), allocatable :: source
 #endif
 
-  call parse_args(rfmip_path, ecckd_path, forcing_index, physics_index, block_size, max_blocks)
+  call parse_args(rfmip_path, ecckd_path, forcing_index, physics_index, block_size, max_blocks, device_resident)
   call read_size(rfmip_path, ncol, nlay, nexp)
   if (block_size <= 0) block_size = ncol * nexp
   if (mod(ncol * nexp, block_size) /= 0) &
@@ -110,9 +116,21 @@ program ecckd_rfmip
   flux_dn = 0._wp
 #ifdef SHORTWAVE
   allocate(mu0(block_size), def_tsi(block_size), toa_flux(block_size, ngpt), usecol(block_size, nblocks))
+  if (device_resident) then
+    allocate(ty_optical_props_2str_dev :: optical_props)
+  else
+    allocate(ty_optical_props_2str :: optical_props)
+  end if
   call stop_on_err(optical_props%alloc_2str(block_size, nlay, ecckd))
   usecol = sza < 90._wp - 2._wp * spacing(90._wp)                          ! ecckd_rfmip_sw.F90:106-108
 #else
+  if (device_resident) then
+    allocate(ty_source_func_lw_dev :: source)
+    allocate(ty_optical_props_1scl_dev :: optical_props)
+  else
+    allocate(ty_source_func_lw :: source)
+    allocate(ty_optical_props_1scl :: optical_props)
+  end if
   call stop_on_err(source%alloc(block_size, nlay, ecckd))
   call stop_on_err(optical_props%alloc_1scl(block_size, nlay, ecckd))
 #endif

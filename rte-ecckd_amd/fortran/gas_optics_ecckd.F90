@@ -22,6 +22,8 @@
 module gas_optics_ecckd
   use, intrinsic :: iso_c_binding
   use mo_gas_concentrations, only: ty_gas_concs
+  use mo_ecckd_device, only: ty_optical_props_1scl_dev, ty_optical_props_2str_dev, ty_source_func_lw_dev, &
+                             ECCKD_HOST, ECCKD_MIXED
   use mo_gas_optics, only: ty_gas_optics
   use mo_optical_props, only: ty_optical_props_arry, ty_optical_props_2str
   use mo_rte_kind, only: wp
@@ -33,7 +35,6 @@ module gas_optics_ecckd
   integer, parameter, public :: linear = 1
   integer, parameter, public :: look_up_table = 2
   integer, parameter, public :: relative_linear = 3
-  integer(c_int), parameter :: ECCKD_HOST = 0
   integer, parameter :: name_len = 32
 
   type, extends(ty_gas_optics), public :: ty_gas_optics_ecckd
@@ -145,7 +146,7 @@ module gas_optics_ecckd
       type(c_ptr), dimension(*), intent(in) :: vmr
       integer(c_long_long), dimension(*), intent(in) :: cs, ls
       real(c_double), dimension(*), intent(in) :: scalar
-      real(c_double), dimension(*), intent(inout) :: tau, lay_source, lev_inc, lev_dec, sfc_source
+      type(c_ptr), value :: tau, lay_source, lev_inc, lev_dec, sfc_source   ! host (ECCKD_HOST) or device (ECCKD_MIXED)
       type(c_ptr), value :: stream
       integer(c_int) :: rc
     end function c_gas_optics_lw
@@ -159,15 +160,14 @@ module gas_optics_ecckd
       type(c_ptr), dimension(*), intent(in) :: vmr
       integer(c_long_long), dimension(*), intent(in) :: cs, ls
       real(c_double), dimension(*), intent(in) :: scalar
-      real(c_double), dimension(*), intent(inout) :: tau
-      type(c_ptr), value :: ssa, g
+      type(c_ptr), value :: tau, ssa, g                                     ! host (ECCKD_HOST) or device (ECCKD_MIXED)
       real(c_double), dimension(*), intent(inout) :: toa_src
       type(c_ptr), value :: stream
       integer(c_int) :: rc
     end function c_gas_optics_sw
   end interface
 
-  public :: c_error_message
+  public :: c_error_message, c_loc_3d, c_loc_2d
 
 contains
 
@@ -282,34 +282,73 @@ contains
     get_temp_max = c_temp_max(this%handle)
   end function get_temp_max
 
-  !> gas_desc -> the flat description the C ABI takes.  Uses only the public ty_gas_concs
-  !! interface (get_num_gases, get_gas_names, get_vmr), as the reference does at :340-351, so the
-  !! same shim works with RTE-RRTMGP's own ty_gas_concs.  vmr(:,:,j) is gas j broadcast to
-  !! (ncol,nlay); a get_vmr error is passed through (:351-354).
-  function marshal_gases(gas_desc, ncol, nlay, names, vmr) result(error_msg)
+  !> gas_desc -> the flat description the C ABI takes, without copying a concentration field: the C ABI takes a
+  !! pointer and two strides per gas, which is exactly what ty_gas_concs stores -- concs(i)%conc is (1,1) for a
+  !! scalar, (1,nlay) for a profile and (ncol,nlay) for a full field (RTE-RRTMGP's mo_gas_concentrations, same
+  !! public components as the minimal type of mo_rte_min.F90), so the broadcast of get_vmr (:351) happens on the
+  !! GPU through the strides.  Like the reference (:348-364) a concentration is only looked up for gases the
+  !! k-distribution holds a table for: the others cross the boundary as a name with a null pointer (nothing is
+  !! staged for them and an unset one is not an error); the get_vmr error texts are kept (:351-354).
+  function marshal_gases(this, gas_desc, ncol, nlay, names, ptr, cs, ls, scalar) result(error_msg)
+    class(ty_gas_optics_ecckd), intent(in) :: this
     type(ty_gas_concs), intent(in) :: gas_desc
     integer, intent(in) :: ncol, nlay
     character(kind=c_char), dimension(:), allocatable, intent(out) :: names
-    real(wp), dimension(:,:,:), allocatable, intent(out) :: vmr
+    type(c_ptr), dimension(:), allocatable, intent(out) :: ptr
+    integer(c_long_long), dimension(:), allocatable, intent(out) :: cs, ls
+    real(c_double), dimension(:), allocatable, intent(out) :: scalar
     character(len=128) :: error_msg
-    character(len=32), dimension(:), allocatable :: gas_names
-    integer :: n, j, k
+    character(len=32), dimension(:), allocatable :: gas_names, model_gases
+    integer :: n, j, k, nm
+    logical :: known
     error_msg = ""
     n = gas_desc%get_num_gases()
-    allocate(gas_names(n))
+    nm = this%get_ngas()
+    allocate(gas_names(n), model_gases(nm))
     gas_names = gas_desc%get_gas_names()
-    allocate(names(max(1, n * name_len)), vmr(ncol, nlay, max(1, n)))
+    model_gases = this%get_gases()
+    allocate(names(max(1, n * name_len)), ptr(max(1, n)), cs(max(1, n)), ls(max(1, n)), scalar(max(1, n)))
     names = " "
+    ptr = c_null_ptr
+    cs = 0_c_long_long
+    ls = 0_c_long_long
+    scalar = 0._c_double
     do j = 1, n
       do k = 1, min(name_len, len_trim(gas_names(j)))
         names((j - 1) * name_len + k) = gas_names(j)(k:k)
       end do
-      error_msg = gas_desc%get_vmr(gas_names(j), vmr(:, :, j))
-      if (trim(error_msg) /= "") return
+      known = .false.
+      do k = 1, nm
+        if (trim(model_gases(k)) == trim(gas_names(j))) known = .true.
+      end do
+      if (.not. known) cycle                                  ! :358-364 silently skipped
+      if (.not. allocated(gas_desc%concs(j)%conc)) then      ! (get_gas_names() returns gas_name(:): index j)
+        error_msg = "ty_gas_concs%get_vmr; gas " // trim(gas_names(j)) // " not found"
+        return
+      end if
+      associate (c => gas_desc%concs(j)%conc)
+        if (size(c, 1) > 1 .and. size(c, 1) /= ncol) then
+          error_msg = "ty_gas_concs%get_vmr; gas " // trim(gas_names(j)) // " array is inconsistent with ncol"
+          return
+        end if
+        if (size(c, 2) > 1 .and. size(c, 2) /= nlay) then
+          error_msg = "ty_gas_concs%get_vmr; gas " // trim(gas_names(j)) // " array is inconsistent with nlay"
+          return
+        end if
+        if (size(c) == 1) then
+          scalar(j) = c(1, 1)
+        else
+          ptr(j) = c_loc_2d(c)
+          if (size(c, 1) > 1) cs(j) = 1_c_long_long
+          if (size(c, 2) > 1) ls(j) = int(size(c, 1), c_long_long)
+        end if
+      end associate
     end do
   end function marshal_gases
 
-  !> gas_optics_int, src/gas_optics_ecckd.f90:381-426 (same argument list).
+  !> gas_optics_int, src/gas_optics_ecckd.f90:381-426 (same argument list).  Host containers: ECCKD_HOST
+  !! (every array is staged through the GPU).  Device twins (mo_ecckd_device): ECCKD_MIXED -- tau and the
+  !! sources stay in HBM for rte_lw.
   function gas_optics_int(this, play, plev, tlay, tsfc, gas_desc, optical_props, sources, col_dry, tlev) &
       result(error_msg)
     class(ty_gas_optics_ecckd), intent(in) :: this
@@ -321,35 +360,62 @@ contains
     character(len=128) :: error_msg
     real(wp), dimension(:,:), intent(in), target, optional :: col_dry, tlev
     character(kind=c_char), dimension(:), allocatable :: names
-    real(wp), dimension(:,:,:), allocatable, target :: vmr
     real(wp), dimension(:,:), allocatable, target :: tlev_c
     type(c_ptr), dimension(:), allocatable :: ptr
     integer(c_long_long), dimension(:), allocatable :: cs, ls
     real(c_double), dimension(:), allocatable :: scalar
-    type(c_ptr) :: tlev_p
-    integer :: ncol, nlay, n, j
-    integer(c_int) :: rc
+    type(c_ptr) :: tlev_p, p_tau, p_lay, p_inc, p_dec, p_sfc
+    integer :: ncol, nlay, n
+    integer(c_int) :: rc, memspace
     ncol = size(tlay, 1)
     nlay = size(tlay, 2)
-    error_msg = marshal_gases(gas_desc, ncol, nlay, names, vmr)
+    error_msg = marshal_gases(this, gas_desc, ncol, nlay, names, ptr, cs, ls, scalar)
     if (trim(error_msg) /= "") return
     n = gas_desc%get_num_gases()
-    allocate(ptr(max(1, n)), cs(max(1, n)), ls(max(1, n)), scalar(max(1, n)))
-    do j = 1, n
-      ptr(j) = c_loc(vmr(1, 1, j))
-    end do
-    cs = 1_c_long_long
-    ls = int(ncol, c_long_long)
-    scalar = 0._c_double
     tlev_p = c_null_ptr
     if (present(tlev)) then
-      allocate(tlev_c(ncol, nlay + 1))
-      tlev_c = tlev
-      tlev_p = c_loc(tlev_c(1, 1))
+      if (is_contiguous(tlev)) then
+        tlev_p = c_loc_2d(tlev)
+      else
+        allocate(tlev_c(ncol, nlay + 1))
+        tlev_c = tlev
+        tlev_p = c_loc(tlev_c(1, 1))
+      end if
     end if
+    memspace = ECCKD_HOST
+    select type (optical_props)
+      class is (ty_optical_props_1scl_dev)
+        select type (sources)
+          class is (ty_source_func_lw_dev)
+            if (optical_props%ncol /= ncol .or. optical_props%nlay /= nlay .or. sources%ncol /= ncol .or. &
+                sources%nlay /= nlay) then
+              error_msg = "gas_optics: device-resident optical_props / sources are inconsistently sized"
+              return
+            end if
+            memspace = ECCKD_MIXED
+            p_tau = optical_props%d_tau
+            p_lay = sources%d_lay_source
+            p_inc = sources%d_lev_source_inc
+            p_dec = sources%d_lev_source_dec
+            p_sfc = sources%d_sfc_source
+          class default
+            error_msg = "gas_optics: device-resident optical_props needs device-resident sources (ty_source_func_lw_dev)"
+            return
+        end select
+      class default
+        select type (sources)
+          class is (ty_source_func_lw_dev)
+            error_msg = "gas_optics: device-resident sources need device-resident optical_props (ty_optical_props_1scl_dev)"
+            return
+        end select
+        p_tau = c_loc_3d(optical_props%tau)
+        p_lay = c_loc_3d(sources%lay_source)
+        p_inc = c_loc_3d(sources%lev_source_inc)
+        p_dec = c_loc_3d(sources%lev_source_dec)
+        p_sfc = c_loc_2d(sources%sfc_source)
+    end select
     rc = c_gas_optics_lw(this%handle, int(ncol, c_int), int(nlay, c_int), plev, tlay, tsfc, tlev_p, &
-                         int(n, c_int), names, ptr, cs, ls, scalar, optical_props%tau, sources%lay_source, &
-                         sources%lev_source_inc, sources%lev_source_dec, sources%sfc_source, ECCKD_HOST, &
+                         int(n, c_int), names, ptr, cs, ls, scalar, p_tau, p_lay, p_inc, p_dec, p_sfc, memspace, &
                          c_null_ptr)
     if (rc /= 0) error_msg = c_error_message()
   end function gas_optics_int
@@ -364,34 +430,42 @@ contains
     real(wp), dimension(:,:), intent(in), target, optional :: col_dry
     character(len=128) :: error_msg
     character(kind=c_char), dimension(:), allocatable :: names
-    real(wp), dimension(:,:,:), allocatable, target :: vmr
     type(c_ptr), dimension(:), allocatable :: ptr
     integer(c_long_long), dimension(:), allocatable :: cs, ls
     real(c_double), dimension(:), allocatable :: scalar
-    type(c_ptr) :: ssa_p, g_p
-    integer :: ncol, nlay, n, j
-    integer(c_int) :: rc
+    type(c_ptr) :: tau_p, ssa_p, g_p
+    integer :: ncol, nlay, n
+    integer(c_int) :: rc, memspace
     ncol = size(tlay, 1)
     nlay = size(tlay, 2)
-    error_msg = marshal_gases(gas_desc, ncol, nlay, names, vmr)
+    error_msg = marshal_gases(this, gas_desc, ncol, nlay, names, ptr, cs, ls, scalar)
     if (trim(error_msg) /= "") return
     n = gas_desc%get_num_gases()
-    allocate(ptr(max(1, n)), cs(max(1, n)), ls(max(1, n)), scalar(max(1, n)))
-    do j = 1, n
-      ptr(j) = c_loc(vmr(1, 1, j))
-    end do
-    cs = 1_c_long_long
-    ls = int(ncol, c_long_long)
-    scalar = 0._c_double
     ssa_p = c_null_ptr
     g_p = c_null_ptr
+    memspace = ECCKD_HOST
     select type (optical_props)                  ! :457-464
-      type is (ty_optical_props_2str)
+      class is (ty_optical_props_2str_dev)
+        if (optical_props%ncol /= ncol .or. optical_props%nlay /= nlay) then
+          error_msg = "gas_optics: device-resident optical_props is inconsistently sized"
+          return
+        end if
+        memspace = ECCKD_MIXED
+        tau_p = optical_props%d_tau
+        ssa_p = optical_props%d_ssa
+        g_p = optical_props%d_g
+      class is (ty_optical_props_1scl_dev)
+        memspace = ECCKD_MIXED
+        tau_p = optical_props%d_tau
+      class is (ty_optical_props_2str)
+        tau_p = c_loc_3d(optical_props%tau)
         ssa_p = c_loc_3d(optical_props%ssa)
         g_p = c_loc_3d(optical_props%g)
+      class default
+        tau_p = c_loc_3d(optical_props%tau)
     end select
     rc = c_gas_optics_sw(this%handle, int(ncol, c_int), int(nlay, c_int), plev, tlay, int(n, c_int), names, &
-                         ptr, cs, ls, scalar, optical_props%tau, ssa_p, g_p, toa_src, ECCKD_HOST, c_null_ptr)
+                         ptr, cs, ls, scalar, tau_p, ssa_p, g_p, toa_src, memspace, c_null_ptr)
     if (rc /= 0) error_msg = c_error_message()
   end function gas_optics_ext
 
@@ -400,5 +474,11 @@ contains
     type(c_ptr) :: p
     p = c_loc(a(1, 1, 1))
   end function c_loc_3d
+
+  function c_loc_2d(a) result(p)
+    real(wp), dimension(:,:), intent(in), target, contiguous :: a
+    type(c_ptr) :: p
+    p = c_loc(a(1, 1))
+  end function c_loc_2d
 
 end module gas_optics_ecckd

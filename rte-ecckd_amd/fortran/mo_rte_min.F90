@@ -15,6 +15,8 @@
 !                          sfc_source, alloc           (:407-424, ecckd_rfmip_lw.F90:102)
 !   mo_fluxes              ty_fluxes_broadband: flux_up, flux_dn, flux_dn_dir pointers
 !                          (ecckd_rfmip_lw.F90:108-109)
+!   mo_fluxes_byband       ty_fluxes_byband: bnd_flux_up, bnd_flux_dn, bnd_flux_dn_dir (ncol,nlev,nband) on top of
+!                          the broadband members (what RTE-RRTMGP callers pass to rte_lw / rte_sw for spectral output)
 !   mo_gas_optics          abstract ty_gas_optics with the deferred interfaces of
 !                          src/gas_optics_ecckd.f90:381-395, 431-442, 487-553
 module mo_rte_kind
@@ -320,6 +322,18 @@ module mo_fluxes
     real(wp), dimension(:,:), pointer :: flux_net => null(), flux_dn_dir => null()
   end type ty_fluxes_broadband
 end module mo_fluxes
+
+
+module mo_fluxes_byband
+  use mo_rte_kind, only: wp
+  use mo_fluxes, only: ty_fluxes_broadband
+  implicit none
+  private
+  type, extends(ty_fluxes_broadband), public :: ty_fluxes_byband
+    real(wp), dimension(:,:,:), pointer :: bnd_flux_up => null(), bnd_flux_dn => null()   ! (ncol,nlay+1,nband)
+    real(wp), dimension(:,:,:), pointer :: bnd_flux_net => null(), bnd_flux_dn_dir => null()
+  end type ty_fluxes_byband
+end module mo_fluxes_byband
 
 
 module mo_gas_optics

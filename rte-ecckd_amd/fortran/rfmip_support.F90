@@ -453,6 +453,7 @@ contains
     write(error_unit, "(a)") " " // "-p [1,2] - Physics index."
     write(error_unit, "(a)") " " // "-b n - Columns per block (default: all columns in one block; the reference uses 1)."
     write(error_unit, "(a)") " " // "-n n - Process only the first n blocks (the reference processes 1700)."
+    write(error_unit, "(a)") " " // "-d - Device-resident optical properties and sources (only inputs and fluxes cross the bus)."
   end subroutine help
 
   !> Gas names in the k-distribution and in the RFMIP file by forcing index (utils.f90:41-70).
@@ -469,16 +470,18 @@ contains
   end subroutine determine_gas_names
 
   !> rfmip_file ecckd_file [-f 1|2] [-p 1|2] [-b block] [-n nblocks] [-h|--help]   (utils.f90:74-134)
-  subroutine parse_args(rfmip_path, ecckd_path, forcing_index, physics_index, block_size, max_blocks)
+  subroutine parse_args(rfmip_path, ecckd_path, forcing_index, physics_index, block_size, max_blocks, device_resident)
     character(len=*), intent(inout) :: rfmip_path, ecckd_path
     integer, intent(inout) :: forcing_index, physics_index
     integer, intent(inout), optional :: block_size, max_blocks
+    logical, intent(inout), optional :: device_resident
     character(len=512) :: buffer
     integer :: i, npos, nargs
     forcing_index = 1
     physics_index = 1
     if (present(block_size)) block_size = 0
     if (present(max_blocks)) max_blocks = 0
+    if (present(device_resident)) device_resident = .false.
     nargs = command_argument_count()
     if (nargs < 2) then
       call usage()
@@ -492,6 +495,8 @@ contains
       case ("-h", "--help")
         call help()
         stop 0
+      case ("-d")
+        if (present(device_resident)) device_resident = .true.
       case ("-f", "-p", "-b", "-n")
         if (i + 1 > nargs) then
           call usage()

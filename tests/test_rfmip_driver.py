@@ -110,6 +110,11 @@ def test_rfmip_lw(pkg, gpu, oracle_mod, tmp_path, flags, f_idx, p_idx):
     assert np.max(np.abs(gu[:, :n] - fu[:, :n])) < 1e-9 and np.max(np.abs(gd[:, :n] - fd[:, :n])) < 1e-9
     if n < NSITE * NEXP:
         assert np.all(gu[:, n:] == 0)                          # unprocessed blocks stay zero, like the reference's 1700
+    # -d: device-resident optical properties and sources (ECCKD_MIXED), the same fluxes bit for bit
+    r = subprocess.run([pkg.RFMIP_LW, "rfmip.nc", LW_FSCK] + flags + ["-d"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_flux(str(tmp_path / ("rlu_Efx_RTE-ecckd_rad-irf_r1i1p%df%d_gn.nc" % (p_idx, f_idx))), "rlu"), gu)
+    assert np.array_equal(read_flux(str(tmp_path / ("rld_Efx_RTE-ecckd_rad-irf_r1i1p%df%d_gn.nc" % (p_idx, f_idx))), "rld"), gd)
 
 
 @pytest.mark.gpu
@@ -135,6 +140,11 @@ def test_rfmip_sw(pkg, gpu, oracle_mod, tmp_path):
     gd = read_flux(str(tmp_path / "rsd_Efx_RTE-ecckd_rad-irf_r1i1p1f1_gn.nc"), "rsd")
     assert np.max(np.abs(gu - fu)) < 1e-9 and np.max(np.abs(gd - fd)) < 1e-9
     assert np.all(gu[:, ~use] == 0) and (~use).sum() > 0
+    # -d: device-resident optical properties, the same fluxes bit for bit
+    r = subprocess.run([pkg.RFMIP_SW, "rfmip.nc", SW_WIDE, "-b", "150", "-d"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_flux(str(tmp_path / "rsu_Efx_RTE-ecckd_rad-irf_r1i1p1f1_gn.nc"), "rsu"), gu)
+    assert np.array_equal(read_flux(str(tmp_path / "rsd_Efx_RTE-ecckd_rad-irf_r1i1p1f1_gn.nc"), "rsd"), gd)
 
 
 def test_rfmip_cli_and_io_errors(pkg, tmp_path):
