@@ -219,6 +219,29 @@ int ecckd_rte_lw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int
                      int memspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * RTE-RRTMGP's KERNEL-level solver interfaces [RTE-ext: mo_rte_solver_kernels.F90 / mo_fluxes_broadband_kernels.F90 of the
+ * v1.5 era; that library is not part of the reference tree -- reference Makefile:19,33 links it]: spectral fluxes
+ * (ncol,nlay+1,ngpt), per-g-point boundary conditions (ncol,ngpt), quadrature passed in, the g-point sum left to
+ * sum_broadband.  include/rte_kernels_hip.h + librte_kernels_hip.so export them under RTE-RRTMGP's own bind(C)
+ * names and by-reference argument lists, so that they can stand in for RTE's kernel objects at link time.  These
+ * are compatibility kernels (one thread per column and g-point); rte_lw / rte_sw callers get the fused solvers.
+ *   inc_flux (LW) / inc_flux_dif (SW): diffuse flux incident at the top, (ncol,ngpt) or NULL
+ *   flux_dir_top (SW): direct flux at the top of the domain, inc_flux*mu0, (ncol,ngpt)
+ * --------------------------------------------------------------------------------------- */
+int ecckd_lw_solver_noscat_gpt(int device, int ncol, int nlay, int ngpt, int top_at_1, int nmus, const double *Ds,
+                               const double *weights, const double *tau, const double *lay_source,
+                               const double *lev_source_inc, const double *lev_source_dec,
+                               const double *sfc_emis, const double *sfc_src, const double *inc_flux,
+                               double *gpt_flux_up, double *gpt_flux_dn, int memspace, void *stream);
+int ecckd_sw_solver_2stream_gpt(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau,
+                                const double *ssa, const double *g, const double *mu0,
+                                const double *flux_dir_top, const double *inc_flux_dif,
+                                const double *sfc_alb_dir, const double *sfc_alb_dif, double *gpt_flux_up,
+                                double *gpt_flux_dn, double *gpt_flux_dir, int memspace, void *stream);
+int ecckd_sum_broadband(int device, int ncol, int nlev, int ngpt, const double *spectral_flux,
+                        double *broadband_flux, int memspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused longwave path (no counterpart call in the reference, whose block loop calls
  * gas_optics and rte_lw back to back with nothing reading tau or the sources in between:
  * ecckd_rfmip_lw.F90:120-135).  The three source arrays are pure functions of tlay / tlev / tsfc and the model's

@@ -357,6 +357,18 @@ void oracle_rte_lw_opt(int ncol, int nlay, int ng, int top_at_1, int nmus, const
                        const double *lev_source_dec, const double *sfc_emis_gpt,
                        const double *sfc_source, const double *inc_flux,
                        const oracle_solver_options_t *opt, double *flux_up, double *flux_dn) {
+  oracle_rte_lw_gpt(ncol, nlay, ng, top_at_1, nmus, tau, lay_source, lev_source_inc, lev_source_dec, sfc_emis_gpt,
+                    sfc_source, inc_flux, opt, flux_up, flux_dn, NULL, NULL);
+}
+
+/* ... and with the spectral fluxes gpt_flux_up / gpt_flux_dn (ncol,nlay+1,ng) that lw_solver_noscat_GaussQuad
+ * itself returns (NULL: not wanted); flux_up / flux_dn (sum_broadband of them) may be NULL too. */
+void oracle_rte_lw_gpt(int ncol, int nlay, int ng, int top_at_1, int nmus, const double *tau,
+                       const double *lay_source, const double *lev_source_inc,
+                       const double *lev_source_dec, const double *sfc_emis_gpt,
+                       const double *sfc_source, const double *inc_flux,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
+                       double *gpt_flux_up, double *gpt_flux_dn) {
   const long n2 = (long)ncol * nlay, n2l = (long)ncol * (nlay + 1);
   double *gup = (double *)malloc(sizeof(double) * n2l), *gdn = (double *)malloc(sizeof(double) * n2l);
   double *rup = (double *)malloc(sizeof(double) * n2l), *rdn = (double *)malloc(sizeof(double) * n2l);
@@ -374,6 +386,9 @@ void oracle_rte_lw_opt(int ncol, int nlay, int ng, int top_at_1, int nmus, const
                        w1 + n2, w1 + 2 * n2, w1 + 3 * n2);
       for (long q = 0; q < n2l; ++q) { gup[q] = gup[q] + rup[q]; gdn[q] = gdn[q] + rdn[q]; }
     }
+    if (gpt_flux_up) memcpy(gpt_flux_up + n2l * k, gup, sizeof(double) * n2l);
+    if (gpt_flux_dn) memcpy(gpt_flux_dn + n2l * k, gdn, sizeof(double) * n2l);
+    if (!flux_up || !flux_dn) continue;
     /* sum_broadband: first g assigns, the rest accumulate in g order */
     if (k == 0) for (long q = 0; q < n2l; ++q) { flux_up[q] = gup[q]; flux_dn[q] = gdn[q]; }
     else for (long q = 0; q < n2l; ++q) { flux_up[q] = flux_up[q] + gup[q]; flux_dn[q] = flux_dn[q] + gdn[q]; }
@@ -397,6 +412,18 @@ void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *t
                        const double *sfc_alb_dir_gpt, const double *sfc_alb_dif_gpt,
                        const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
                        double *flux_dir) {
+  oracle_rte_sw_gpt(ncol, nlay, ng, top_at_1, tau, ssa, g, mu0, toa, NULL, sfc_alb_dir_gpt, sfc_alb_dif_gpt, opt, flux_up,
+                    flux_dn, flux_dir, NULL, NULL, NULL);
+}
+
+/* ... with the diffuse incident flux inc_flux_dif(ncol,ng) (NULL: none) and the spectral fluxes (ncol,nlay+1,ng)
+ * that sw_solver_2stream itself returns (NULL: not wanted; the broadband outputs may be NULL too). */
+void oracle_rte_sw_gpt(int ncol, int nlay, int ng, int top_at_1, const double *tau,
+                       const double *ssa, const double *g, const double *mu0, const double *toa,
+                       const double *inc_flux_dif, const double *sfc_alb_dir_gpt,
+                       const double *sfc_alb_dif_gpt, const oracle_solver_options_t *opt,
+                       double *flux_up, double *flux_dn, double *flux_dir, double *gpt_flux_up,
+                       double *gpt_flux_dn, double *gpt_flux_dir) {
   const double eps = 2.220446049250313e-16;
   const long n2l = (long)ncol * (nlay + 1);
   double *Rdif = (double *)malloc(sizeof(double) * nlay * 9 + sizeof(double) * (nlay + 1) * 6);
@@ -405,7 +432,8 @@ void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *t
   double *spare = denom + nlay;
   double *albedo = spare + nlay, *src = albedo + (nlay + 1), *fdir = src + (nlay + 1);
   double *fdn = fdir + (nlay + 1), *fup = fdn + (nlay + 1);
-  for (long q = 0; q < n2l; ++q) { flux_up[q] = 0.; flux_dn[q] = 0.; if (flux_dir) flux_dir[q] = 0.; }
+  if (flux_up && flux_dn)
+    for (long q = 0; q < n2l; ++q) { flux_up[q] = 0.; flux_dn[q] = 0.; if (flux_dir) flux_dir[q] = 0.; }
   for (int k = 0; k < ng; ++k) {
     for (int i = 0; i < ncol; ++i) {
       const double m0 = mu0[i], mu0_inv = 1. / m0;
@@ -457,7 +485,7 @@ void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *t
         albedo[s] = Rdif[l] + Tdif[l] * Tdif[l] * albedo[s + 1] * denom[s];
         src[s] = src_up[s] + Tdif[l] * denom[s] * (src[s + 1] + albedo[s + 1] * src_dn[s]);
       }
-      fdn[0] = 0.;
+      fdn[0] = inc_flux_dif ? inc_flux_dif[i + (long)ncol * k] : 0.;
       fup[0] = fdn[0] * albedo[0] + src[0];
       for (int s = 1; s <= nlay; ++s) {
         const int l = top_at_1 ? s - 1 : nlay - s;
@@ -467,6 +495,10 @@ void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *t
       for (int s = 0; s <= nlay; ++s) {
         const long q = i + (long)ncol * (top + step * s);
         const double dn = fdn[s] + fdir[s];
+        if (gpt_flux_up) gpt_flux_up[q + n2l * k] = fup[s];
+        if (gpt_flux_dn) gpt_flux_dn[q + n2l * k] = dn;
+        if (gpt_flux_dir) gpt_flux_dir[q + n2l * k] = fdir[s];
+        if (!flux_up || !flux_dn) continue;
         if (k == 0) { flux_up[q] = fup[s]; flux_dn[q] = dn; if (flux_dir) flux_dir[q] = fdir[s]; }
         else {
           flux_up[q] = flux_up[q] + fup[s]; flux_dn[q] = flux_dn[q] + dn;

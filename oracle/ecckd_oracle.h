@@ -126,6 +126,21 @@ void oracle_rte_sw_opt(int ncol, int nlay, int ng, int top_at_1, const double *t
                        const double *sfc_alb_dir_gpt, const double *sfc_alb_dif_gpt,
                        const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
                        double *flux_dir);
+/* The same with the spectral fluxes (ncol,nlay+1,ng) that RTE-RRTMGP's kernels lw_solver_noscat_GaussQuad /
+ * sw_solver_2stream return before sum_broadband (any output may be NULL), and the shortwave's diffuse incident
+ * flux inc_flux_dif(ncol,ng) (NULL: none). */
+void oracle_rte_lw_gpt(int ncol, int nlay, int ng, int top_at_1, int nmus, const double *tau,
+                       const double *lay_source, const double *lev_source_inc,
+                       const double *lev_source_dec, const double *sfc_emis_gpt,
+                       const double *sfc_source, const double *inc_flux,
+                       const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
+                       double *gpt_flux_up, double *gpt_flux_dn);
+void oracle_rte_sw_gpt(int ncol, int nlay, int ng, int top_at_1, const double *tau,
+                       const double *ssa, const double *g, const double *mu0, const double *toa,
+                       const double *inc_flux_dif, const double *sfc_alb_dir_gpt,
+                       const double *sfc_alb_dif_gpt, const oracle_solver_options_t *opt,
+                       double *flux_up, double *flux_dn, double *flux_dir, double *gpt_flux_up,
+                       double *gpt_flux_dn, double *gpt_flux_dir);
 
 /* RTE-RRTMGP rte_sw, two-stream + adding; albedos are (ncol,ng). flux_dn includes direct. */
 void oracle_rte_sw(int ncol, int nlay, int ng, int top_at_1, const double *tau,

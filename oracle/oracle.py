@@ -290,6 +290,34 @@ def rte_sw(tau, ssa, g, mu0, toa, alb_dir_gpt, alb_dif_gpt, top_at_1=True, optio
     return fu, fd, fdir
 
 
+def rte_lw_gpt(tau, lay_source, lev_source_inc, lev_source_dec, sfc_emis_gpt, sfc_source, top_at_1=True, nmus=1,
+               inc_flux=None, options=None):
+    """Spectral fluxes (ng, nlay+1, ncol) as lw_solver_noscat_GaussQuad returns them, before sum_broadband."""
+    ng, nlay, ncol = tau.shape
+    gu = np.empty((ng, nlay + 1, ncol))
+    gd = np.empty_like(gu)
+    opt = options if options is not None else solver_options()
+    inc = None if inc_flux is None else _f64(inc_flux)
+    lib().oracle_rte_lw_gpt(ncol, nlay, ng, int(top_at_1), nmus, _p(_f64(tau)), _p(_f64(lay_source)),
+                            _p(_f64(lev_source_inc)), _p(_f64(lev_source_dec)), _p(_f64(sfc_emis_gpt)),
+                            _p(_f64(sfc_source)), _p(inc), C.byref(opt), None, None, _p(gu), _p(gd))
+    return gu, gd
+
+
+def rte_sw_gpt(tau, ssa, g, mu0, toa, alb_dir_gpt, alb_dif_gpt, top_at_1=True, inc_flux_dif=None, options=None):
+    """Spectral fluxes (ng, nlay+1, ncol) up, down (total), direct as sw_solver_2stream returns them."""
+    ngp, nlay, ncol = tau.shape
+    gu = np.empty((ngp, nlay + 1, ncol))
+    gd = np.empty_like(gu)
+    gr = np.empty_like(gu)
+    opt = options if options is not None else solver_options()
+    dif = None if inc_flux_dif is None else _f64(inc_flux_dif)
+    lib().oracle_rte_sw_gpt(ncol, nlay, ngp, int(top_at_1), _p(_f64(tau)), _p(_f64(ssa)), _p(_f64(g)),
+                            _p(_f64(mu0)), _p(_f64(toa)), _p(dif), _p(_f64(alb_dir_gpt)), _p(_f64(alb_dif_gpt)),
+                            C.byref(opt), None, None, None, _p(gu), _p(gd), _p(gr))
+    return gu, gd, gr
+
+
 def lw_pipeline(model, plev, tlay, tlev, tsfc, gases, sfc_emis, block=1, nthreads=1, nmus=1):
     """gas_optics_int + rte_lw block by block (ecckd_rfmip_lw.F90:107-136)."""
     plev, tlay, tlev, tsfc, sfc_emis = map(_f64, (plev, tlay, tlev, tsfc, sfc_emis))

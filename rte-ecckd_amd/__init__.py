@@ -34,10 +34,13 @@ HOST, DEVICE = 0, 1
 NAME_LEN = 32
 
 _SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_lw_split.hip",
-            "kernels_rte_sw.hip",
+            "kernels_rte_sw.hip", "kernels_rte_gpt.hip",
             "capi.cpp", "nc_capi.cpp", "model.cpp", "cdf1.cpp"]
 _HEADERS = ["kernels.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h"),
-            os.path.join("..", "..", "include", "ecckd_nc.h")]
+            os.path.join("..", "..", "include", "ecckd_nc.h"), os.path.join("..", "..", "include", "rte_kernels_hip.h")]
+# second library: RTE-RRTMGP's kernel-level bind(C) names over the C ABI of the first (include/rte_kernels_hip.h)
+RTE_KERNELS_LIB = os.path.join(_HERE, "librte_kernels_hip.so")
+_RTE_KERNELS_SRC = "rte_kernels_capi.cpp"
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -45,9 +48,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_CSRC, h) for h in _HEADERS]
-    if not force and os.path.exists(LIB_PATH):
-        t = os.path.getmtime(LIB_PATH)
+    deps = srcs + [os.path.join(_CSRC, h) for h in _HEADERS] + [os.path.join(_CSRC, _RTE_KERNELS_SRC)]
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(RTE_KERNELS_LIB):
+        t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(RTE_KERNELS_LIB))
         if all(os.path.getmtime(d) <= t for d in deps):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -69,6 +72,11 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", RTE_KERNELS_LIB, os.path.join(_CSRC, _RTE_KERNELS_SRC),
+           "-L" + _HERE, "-lrte_ecckd_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

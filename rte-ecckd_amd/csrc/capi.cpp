@@ -1166,6 +1166,126 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   return 0;
 }
 
+// ---- RTE-RRTMGP's kernel-level interfaces: spectral fluxes (ncol,nlay+1,ngpt), sum_broadband ----
+
+namespace {
+void fill_gpt_options(ecckd::RteGptArgs &a) {
+  const double t = g_opt.lw_tau_thresh.load();
+  a.tau_thresh = t > 0. ? t : std::sqrt(2.220446049250313e-16);
+  a.series3 = g_opt.lw_series_terms.load() == 3;
+  a.inc_isotropic = g_opt.lw_inc_flux_isotropic.load();
+  a.k_floor = g_opt.sw_k_floor.load();
+  a.dir_clamp = g_opt.sw_dir_clamp.load();
+}
+}  // namespace
+
+int ecckd_lw_solver_noscat_gpt(int device, int ncol, int nlay, int ngpt, int top_at_1, int nmus, const double *Ds,
+                               const double *weights, const double *tau, const double *lay_source,
+                               const double *lev_source_inc, const double *lev_source_dec, const double *sfc_emis,
+                               const double *sfc_src, const double *inc_flux, double *gpt_flux_up, double *gpt_flux_dn,
+                               int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  if (ngpt < 1) return fail("ecckd_lw_solver_noscat_gpt: bad ngpt");
+  if (nmus < 1 || nmus > 4 || !Ds || !weights) return fail("ecckd_lw_solver_noscat_gpt: 1..4 quadrature angles with Ds and weights");
+  if (!tau || !lay_source || !lev_source_inc || !lev_source_dec || !sfc_emis || !sfc_src || !gpt_flux_up || !gpt_flux_dn)
+    return fail("ecckd_lw_solver_noscat_gpt: null argument");
+  if (check_device(device)) return 1;
+  if (ncol == 0) return 0;
+  ecckd::RteGptArgs a{};
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = nmus;
+  for (int k = 0; k < nmus; ++k) { a.Ds[k] = Ds[k]; a.wts[k] = weights[k]; }
+  fill_gpt_options(a);
+  const size_t n3 = (size_t)ncol * nlay * ngpt, n2 = (size_t)ncol * ngpt, nf = (size_t)ncol * (nlay + 1) * ngpt;
+  if (memspace == ECCKD_DEVICE) {
+    a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc; a.lev_source_dec = lev_source_dec;
+    a.sfc_emis = sfc_emis; a.sfc_src = sfc_src; a.inc_flux = inc_flux; a.flux_up = gpt_flux_up; a.flux_dn = gpt_flux_dn;
+    ProfScope prof("lw_gpt", static_cast<hipStream_t>(stream));
+    HIPCHK(ecckd::launch_lw_gpt(a, static_cast<hipStream_t>(stream)));
+    return 0;
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  Arena &ar = g_solver_arena[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  if (ar.ensure(align256(n3 * 8) * 4 + align256(n2 * 8) * 3 + align256(nf * 8) * 2)) return 1;
+  Bump b(ar.p);
+  double *d_tau = b.take(n3), *d_lay = b.take(n3), *d_inc = b.take(n3), *d_dec = b.take(n3);
+  double *d_emis = b.take(n2), *d_src = b.take(n2), *d_incf = b.take(n2), *d_up = b.take(nf), *d_dn = b.take(nf);
+  hipStream_t s = nullptr;
+  if (h2d(d_tau, tau, n3, s) || h2d(d_lay, lay_source, n3, s) || h2d(d_inc, lev_source_inc, n3, s) ||
+      h2d(d_dec, lev_source_dec, n3, s) || h2d(d_emis, sfc_emis, n2, s) || h2d(d_src, sfc_src, n2, s))
+    return 1;
+  if (inc_flux && h2d(d_incf, inc_flux, n2, s)) return 1;
+  a.tau = d_tau; a.lay_source = d_lay; a.lev_source_inc = d_inc; a.lev_source_dec = d_dec; a.sfc_emis = d_emis;
+  a.sfc_src = d_src; a.inc_flux = inc_flux ? d_incf : nullptr; a.flux_up = d_up; a.flux_dn = d_dn;
+  HIPCHK(ecckd::launch_lw_gpt(a, s));
+  if (d2h(gpt_flux_up, d_up, nf, s) || d2h(gpt_flux_dn, d_dn, nf, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ecckd_sw_solver_2stream_gpt(int device, int ncol, int nlay, int ngpt, int top_at_1, const double *tau, const double *ssa,
+                                const double *g, const double *mu0, const double *flux_dir_top, const double *inc_flux_dif,
+                                const double *sfc_alb_dir, const double *sfc_alb_dif, double *gpt_flux_up, double *gpt_flux_dn,
+                                double *gpt_flux_dir, int memspace, void *stream) {
+  if (check_dims(ncol, nlay)) return 1;
+  if (ngpt < 1) return fail("ecckd_sw_solver_2stream_gpt: bad ngpt");
+  if (!tau || !ssa || !g || !mu0 || !flux_dir_top || !sfc_alb_dir || !sfc_alb_dif || !gpt_flux_up || !gpt_flux_dn)
+    return fail("ecckd_sw_solver_2stream_gpt: null argument");
+  if (check_device(device)) return 1;
+  if (ncol == 0) return 0;
+  ecckd::RteGptArgs a{};
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = 1;
+  fill_gpt_options(a);
+  const size_t n3 = (size_t)ncol * nlay * ngpt, n2 = (size_t)ncol * ngpt, nf = (size_t)ncol * (nlay + 1) * ngpt;
+  if (memspace == ECCKD_DEVICE) {
+    a.tau = tau; a.ssa = ssa; a.g = g; a.mu0 = mu0; a.fdir_top = flux_dir_top; a.inc_dif = inc_flux_dif;
+    a.alb_dir = sfc_alb_dir; a.alb_dif = sfc_alb_dif; a.flux_up = gpt_flux_up; a.flux_dn = gpt_flux_dn; a.flux_dir = gpt_flux_dir;
+    ProfScope prof("sw_gpt", static_cast<hipStream_t>(stream));
+    HIPCHK(ecckd::launch_sw_gpt(a, static_cast<hipStream_t>(stream)));
+    return 0;
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  Arena &ar = g_solver_arena[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  if (ar.ensure(align256(n3 * 8) * 3 + align256((size_t)ncol * 8) + align256(n2 * 8) * 4 + align256(nf * 8) * 3)) return 1;
+  Bump b(ar.p);
+  double *d_tau = b.take(n3), *d_ssa = b.take(n3), *d_g = b.take(n3), *d_mu0 = b.take(ncol);
+  double *d_top = b.take(n2), *d_dif = b.take(n2), *d_ad = b.take(n2), *d_af = b.take(n2);
+  double *d_up = b.take(nf), *d_dn = b.take(nf), *d_dir = b.take(nf);
+  hipStream_t s = nullptr;
+  if (h2d(d_tau, tau, n3, s) || h2d(d_ssa, ssa, n3, s) || h2d(d_g, g, n3, s) || h2d(d_mu0, mu0, ncol, s) ||
+      h2d(d_top, flux_dir_top, n2, s) || h2d(d_ad, sfc_alb_dir, n2, s) || h2d(d_af, sfc_alb_dif, n2, s))
+    return 1;
+  if (inc_flux_dif && h2d(d_dif, inc_flux_dif, n2, s)) return 1;
+  a.tau = d_tau; a.ssa = d_ssa; a.g = d_g; a.mu0 = d_mu0; a.fdir_top = d_top; a.inc_dif = inc_flux_dif ? d_dif : nullptr;
+  a.alb_dir = d_ad; a.alb_dif = d_af; a.flux_up = d_up; a.flux_dn = d_dn; a.flux_dir = gpt_flux_dir ? d_dir : nullptr;
+  HIPCHK(ecckd::launch_sw_gpt(a, s));
+  if (d2h(gpt_flux_up, d_up, nf, s) || d2h(gpt_flux_dn, d_dn, nf, s)) return 1;
+  if (gpt_flux_dir && d2h(gpt_flux_dir, d_dir, nf, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ecckd_sum_broadband(int device, int ncol, int nlev, int ngpt, const double *spectral_flux, double *broadband_flux,
+                        int memspace, void *stream) {
+  if (ncol < 0 || nlev < 1 || ngpt < 1) return fail("ecckd_sum_broadband: bad dimensions");
+  if (!spectral_flux || !broadband_flux) return fail("ecckd_sum_broadband: null argument");
+  const size_t n = (size_t)ncol * nlev;
+  if (n == 0) return 0;
+  if (memspace == ECCKD_HOST) {   // a sum over ngpt planes: not worth a round trip over the bus
+    for (size_t i = 0; i < n; ++i) {
+      double acc = 0.;
+      for (int k = 0; k < ngpt; ++k) acc += spectral_flux[(size_t)k * n + i];
+      broadband_flux[i] = acc;
+    }
+    return 0;
+  }
+  if (memspace != ECCKD_DEVICE) return fail("ecckd: bad memspace");
+  if (check_device(device)) return 1;
+  HIPCHK(ecckd::launch_sum_planes(spectral_flux, ngpt, n, broadband_flux, 0, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 // ---- fused longwave: tau-only gas optics + solver that recomputes the Planck sources ----
 
 int ecckd_gas_optics_lw_tau(const ecckd_model_t *m, int ncol, int nlay, const double *plev, const double *tlay, int ngas,

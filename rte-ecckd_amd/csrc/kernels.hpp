@@ -124,6 +124,22 @@ struct RteSwArgs {
   int dir_clamp;               // 1: Rdir/Tdir energy clamps of later RTE-RRTMGP releases
 };
 
+// Spectral-output solvers (kernels_rte_gpt.hip): RTE-RRTMGP's kernel-level interfaces.  LW uses tau, lay_source,
+// lev_source_*, sfc_emis(ncol,ng), sfc_src(ncol,ng), inc_flux(ncol,ng)|null, Ds/wts; SW uses tau, ssa, g, mu0(ncol),
+// fdir_top(ncol,ng) (direct flux at the top = toa*mu0), inc_dif(ncol,ng)|null, alb_dir/alb_dif(ncol,ng).
+// flux_up / flux_dn / flux_dir are (ncol,nlay+1,ng).
+struct RteGptArgs {
+  int ncol, nlay, ng, top_at_1, nmus;
+  double Ds[4], wts[4];
+  const double *tau, *lay_source, *lev_source_inc, *lev_source_dec, *sfc_emis, *sfc_src, *inc_flux;
+  const double *ssa, *g, *mu0, *fdir_top, *inc_dif, *alb_dir, *alb_dif;
+  double *flux_up, *flux_dn, *flux_dir;
+  double tau_thresh, k_floor;
+  int series3, inc_isotropic, dir_clamp;
+};
+hipError_t launch_lw_gpt(const RteGptArgs &a, hipStream_t s);
+hipError_t launch_sw_gpt(const RteGptArgs &a, hipStream_t s);
+
 // Host-side helpers -------------------------------------------------------------------------
 int tau_slab_rows(int ng, int np, int nt, int nbil, int nv_lut);   // R that fits LDS (>= 0)
 size_t tau_lds_bytes(int ng, int np, int nt, int nbil, int nv_lut, int R);

@@ -774,13 +774,20 @@ int pick_nb(int nbil) {
 template <typename real, int MODE>
 hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp, hipStream_t s) {
   const int ng = a.tau.ng;
+  if (anyclamp && ng % 4 == 0) return launch_one<real, 4, kTauPassGases, true, true, MODE>(a, lds, s);
   if (anyclamp) return launch_one<real, 4, kTauPassGases, false, true, MODE>(a, lds, s);
   if (NBsel == 7 && ng % 8 == 0) return launch_one<real, 8, 7, true, false, MODE>(a, lds, s);
   if (NBsel == 7 && ng % 4 == 0) return launch_one<real, 4, 7, true, false, MODE>(a, lds, s);
+  if (NBsel == 5 && ng % 4 == 0) return launch_one<real, 4, 5, true, false, MODE>(a, lds, s);
   if (NBsel == 5) return launch_one<real, 4, 5, false, false, MODE>(a, lds, s);
+  if (ng % 4 == 0) return launch_one<real, 4, kTauPassGases, true, false, MODE>(a, lds, s);
   return launch_one<real, 4, kTauPassGases, false, false, MODE>(a, lds, s);
 }
 
+// (FULL = true instantiations -- g-point count a multiple of the chunk, true for both longwave tables -- carry no
+// per-g-point bounds checks and keep everything in registers; the FULL = false ones spill 13-108 VGPRs and only
+// serve tables whose g-point count is not a multiple of 4, e.g. the 27 g-points of the shortwave table with
+// more than 7 gases.)
 // (GC, NB) of the instantiation launch_mode() will pick
 void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
   const int nb = pick_nb(nbil);

@@ -69,8 +69,8 @@ __device__ __forceinline__ double planck_at(const PlanckTab &P, double T, int g,
   return fma(fma(-q, pi, v), rpi, q);
 }
 
-template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK>
-__global__ void __launch_bounds__(64 * NW, ECCKD_SPLIT_WAVES_PER_SIMD) rte_lw_split_kernel(const RteLwArgs a, const PlanckTab pt,
+template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK, int WPS>
+__global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwArgs a, const PlanckTab pt,
                                                                                           const double *tlay, const double *tlev,
                                                                                           const double *tsfc) {
   constexpr int GW = 64 / CW;
@@ -257,15 +257,15 @@ __global__ void __launch_bounds__(64 * NW, ECCKD_SPLIT_WAVES_PER_SIMD) rte_lw_sp
   }
 }
 
-template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK>
+template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK, int WPS = ECCKD_SPLIT_WAVES_PER_SIMD>
 hipError_t launch_split(const RteLwArgs &a, const PlanckTab &pt, const double *tlay, const double *tlev, const double *tsfc,
                         hipStream_t s) {
-  auto k = rte_lw_split_kernel<SEG, NW, CW, SHARED, SER3, PLANCK>;
+  auto k = rte_lw_split_kernel<SEG, NW, CW, SHARED, SER3, PLANCK, WPS>;
   const size_t lds = sizeof(double) * (2 * (size_t)(SEG * NW + 1) * CW + 2 * NW * 3 * 64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   long tiles = ((long)a.ncol + CW - 1) / CW;
-  const long cap = 256L * ECCKD_SPLIT_WAVES_PER_SIMD * 4;   // four rounds of resident blocks; the rest by grid stride
+  const long cap = 256L * WPS * 4;   // four rounds of resident blocks; the rest by grid stride
   if (tiles > cap) tiles = cap;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64 * NW), lds, s, a, pt, tlay, tlev, tsfc);
   return hipGetLastError();
@@ -280,10 +280,15 @@ bool rte_lw_split_applies(const RteLwArgs &a) {
 template <bool SHARED, bool SER3, bool PLANCK>
 static hipError_t launch_seg(const RteLwArgs &a, const PlanckTab &pt, const double *tlay, const double *tlev, const double *tsfc,
                              hipStream_t s) {
+  // The Planck-recomputing form needs 244 VGPRs: 15 layers per wave, two waves per SIMD (three spill 25-54 registers)
+  if constexpr (PLANCK) {
+    return launch_split<15, 4, 32, SHARED, SER3, PLANCK, 2>(a, pt, tlay, tlev, tsfc, s);
+  } else {
   switch (a.split_seg) {   // layers per wave: 10 (6 waves per block, 157 VGPRs, 12 waves per CU), 12 or 15
     case 15: return launch_split<15, 4, 32, SHARED, SER3, PLANCK>(a, pt, tlay, tlev, tsfc, s);
     case 12: return launch_split<12, 5, 32, SHARED, SER3, PLANCK>(a, pt, tlay, tlev, tsfc, s);
     default: return launch_split<10, 6, 32, SHARED, SER3, PLANCK>(a, pt, tlay, tlev, tsfc, s);
+  }
   }
 }
 

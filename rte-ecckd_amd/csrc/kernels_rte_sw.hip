@@ -27,7 +27,14 @@ __device__ __forceinline__ double gsum(double v) {
 }
 
 #ifndef ECCKD_SW_WAVES
-#define ECCKD_SW_WAVES 4096   // 16 waves per CU (121 VGPRs): measured 15 % faster than 2048
+#define ECCKD_SW_WAVES 4096   // 12 waves per CU are resident (143 VGPRs); a grid of 4096 measured 15 % faster than 2048
+#endif
+// Registers: the kernel needs 143 VGPRs, i.e. three waves per SIMD (12 per CU).  Forcing it under 128 for four waves
+// per SIMD was measured in round 2 (same box, tools/ab.py): with the compiler's 2-9 spills 3.80-3.88 ms, with a prefetch
+// depth of 2 (no spill) 3.81-3.85 ms, against 3.78 ms as is -- the kernel is bound by fp64 issue, which three waves per
+// SIMD already saturate (tools/ubench.hip: 0.74 of 0.86 wave-instructions/clk/CU), so the allocation is left alone.
+#ifndef ECCKD_SW_WAVES_PER_SIMD
+#define ECCKD_SW_WAVES_PER_SIMD 3
 #endif
 #ifndef ECCKD_SW_CW
 #define ECCKD_SW_CW 16
@@ -104,7 +111,7 @@ __device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq
 // arithmetic (0.25 VALU wave-instr/clk/CU of 0.81 available at this occupancy): measured 4.52 ms
 // stored vs 3.85 ms recomputed per 1e5 columns x 27 g-points (recomputed: 52 % of the fp64 VALU rate).
 template <int CW, bool RECOMPUTE, bool FAST, bool CLAMP>
-__global__ void __launch_bounds__(64) rte_sw_kernel(const RteSwArgs a) {
+__global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(const RteSwArgs a) {
   constexpr int GW = 64 / CW;
   extern __shared__ double acc[];   // [3][nlay+1][CW]: up, dn, dir
   const int lane = threadIdx.x;

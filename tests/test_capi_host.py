@@ -19,6 +19,12 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(L, s), s
     assert b"gfx950" in L.ecckd_build_info()
+    # the second library: RTE-RRTMGP's kernel-level bind(C) names (include/rte_kernels_hip.h)
+    K = C.CDLL(pkg.RTE_KERNELS_LIB)
+    names = entry.rte_kernel_symbols()
+    assert names == ["lw_solver_noscat_GaussQuad", "net_broadband_precalc", "sum_broadband", "sw_solver_2stream"]
+    for s in names:
+        assert hasattr(K, s), s
 
 
 @pytest.mark.parametrize("path", [LW_FSCK, LW_RRTMGP, SW_WIDE])
@@ -247,3 +253,36 @@ def test_bench_default_shard_size_for_8_gpus():
     import bench
     assert bench.columns_per_gpu(8, None) == 1250000 and bench.columns_per_gpu(1, None) == 1000000
     assert bench.columns_per_gpu(2, None) == 1000000 and bench.columns_per_gpu(4, 300000) == 300000
+
+
+def test_code_object_resources(pkg):
+    """Register allocation of the built gfx950 code objects, read from their own metadata (tools/kernel_resources.py; no
+    GPU needed): the instantiations the BASELINE workloads take keep everything in registers."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels(pkg.LIB_PATH)
+    assert len(ks) > 60
+    seen = set()
+    for name, k in ks.items():
+        m = re.search(r"(gas_fused_kernel|rte_lw_kernel|rte_lw_split_kernel|rte_sw_kernel|tau_kernel)<([^>]*)>", name)
+        if not m:
+            continue
+        kind, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
+        seen.add(kind)
+        if kind == "gas_fused_kernel" and targs[3] == "true":
+            # FULL: g-point count a multiple of the chunk -- both longwave tables (32, 36 g-points), 5 / 7 / 10 gas slots,
+            # with or without per-g-point clamping, every mode and precision
+            assert k["spill_vgpr"] == 0, name
+        if kind == "rte_lw_kernel" or kind == "rte_sw_kernel":
+            assert k["spill_vgpr"] == 0, name
+        if kind == "rte_lw_split_kernel" and targs[0] in ("10", "12") and targs[5] == "false":
+            assert k["spill_vgpr"] == 0, name
+        if kind == "rte_lw_split_kernel" and targs[5] == "true":      # Planck-recomputing form: two waves per SIMD, no spill
+            assert targs[0] == "15" and targs[6] == "2" and k["spill_vgpr"] == 0, name
+    assert seen == {"gas_fused_kernel", "rte_lw_kernel", "rte_lw_split_kernel", "rte_sw_kernel", "tau_kernel"}
+    head = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1>" in n]
+    assert len(head) == 1 and head[0]["vgpr"] <= 256 and kernel_resources.waves_per_simd(head[0]) == 2
+    sw = [k for n, k in ks.items() if "rte_sw_kernel<16, true, true, false>" in n]
+    assert len(sw) == 1 and kernel_resources.waves_per_simd(sw[0]) == 3       # 143 VGPRs: 12 waves per CU (DESIGN 5.4)

@@ -580,14 +580,12 @@ def test_fused_lw_path_vs_oracle(pkg, gpu, oracle_mod, lw, split_solver, seg):
         assert k.lw_fluxes(cols["plev"], cols["tlay"], cols["tsfc"], cols["tlev"], hgc, True, np.ascontiguousarray(emis), hfl,
                            n_gauss_angles=nmus, inc_flux=inc) == ""
         assert np.array_equal(hfl.flux_up, dev_up)
-    # bottom-up storage
+    # bottom-up storage, solver only: the reference's gas optics takes the pressure difference plev(:,j+1) - plev(:,j)
+    # as the layer mass (:143), i.e. it assumes the top at index 1 itself, so only the solver has another orientation
     f2 = lambda a: np.ascontiguousarray(a[::-1])
-    f3 = lambda a: np.ascontiguousarray(a[:, ::-1, :])
-    rc = dict(cols); rc["plev"], rc["tlev"], rc["tlay"] = f2(cols["plev"]), f2(cols["tlev"]), f2(cols["tlay"])
-    rc["h2o"], rc["o3"] = f2(cols["h2o"]), f2(cols["o3"])
-    rgc = helpers.product_gas_concs(pkg, rc, t)
+    op.tau = t(np.ascontiguousarray(otau[:, ::-1, :]))
     fl.flux_up.zero_()
-    assert k.lw_fluxes(t(rc["plev"]), t(rc["tlay"]), tsfc, t(rc["tlev"]), rgc, False, t(emis), fl) == ""
+    assert k.rte_lw_fused(op, False, t(f2(cols["tlay"])), t(f2(cols["tlev"])), tsfc, t(emis), fl) == ""
     fu, fd = oracle_mod.rte_lw(otau, olay, oinc, odec, np.repeat(emis.T, ng, 0), osfc)
     ok = np.isfinite(fu)
     assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)[ok]) < FLUX_ATOL
@@ -596,3 +594,62 @@ def test_fused_lw_path_vs_oracle(pkg, gpu, oracle_mod, lw, split_solver, seg):
     op5 = pkg.OpticalProps1scl(); op5.tau = t(np.zeros((ng, 5, 8))); op5.band2gpt = k.get_band2gpt()
     fl5 = pkg.FluxesBroadband(torch.zeros((6, 8), dtype=torch.float64, device=gpu), torch.zeros((6, 8), dtype=torch.float64, device=gpu))
     assert "60 layers" in k.rte_lw_fused(op5, True, t(np.full((5, 8), 250.)), t(np.full((6, 8), 250.)), t(np.full(8, 250.)), t(np.ones((8, 1))), fl5)
+
+
+# ------------------------------------------------------------------------------------------------
+# RTE-RRTMGP's kernel-level bind(C) interfaces (librte_kernels_hip.so, include/rte_kernels_hip.h)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("top_at_1,nmus", [(True, 1), (False, 3)])
+def test_rte_kernel_level_interfaces(pkg, gpu, oracle_mod, top_at_1, nmus):
+    """lw_solver_noscat_GaussQuad, sw_solver_2stream, sum_broadband, net_broadband_precalc called the way a Fortran
+    bind(C) interface without VALUE calls them (every argument by reference, logical(wl) as C bool, host arrays, the
+    incident fluxes parked in the top level of flux_dn / flux_dir): spectral fluxes against the oracle's."""
+    import ctypes as C
+    K = C.CDLL(pkg.RTE_KERNELS_LIB)
+    rng = np.random.default_rng(21)
+    ncol, nlay, ng = 150, 37, 5
+    top = 0 if top_at_1 else nlay
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    I = lambda v: C.byref(C.c_int(v))
+    B = C.byref(C.c_bool(top_at_1))
+    # ---- longwave ----
+    tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay, inc, dec = (rng.uniform(1, 9, (ng, nlay, ncol)) for _ in range(3))
+    sfc = rng.uniform(1, 9, (ng, ncol)); emis = rng.uniform(0.7, 1.0, (ng, ncol)); incf = rng.uniform(0, 20, (ng, ncol))
+    Ds = np.array([[1.66], [1.18350343, 2.81649655], [1.09719858, 1.69338507, 4.70941630]][nmus - 1])
+    wts = np.array([[0.5], [0.3180413817, 0.1819586183], [0.2009319137, 0.2292411064, 0.0698269799]][nmus - 1])
+    fu = np.zeros((ng, nlay + 1, ncol)); fd = np.zeros((ng, nlay + 1, ncol))
+    fd[:, top, :] = incf                                            # RTE's apply_BC
+    K.lw_solver_noscat_GaussQuad(I(ncol), I(nlay), I(ng), B, I(nmus), P(Ds), P(wts), P(tau), P(lay), P(inc), P(dec), P(emis),
+                                 P(sfc), P(fu), P(fd))
+    ou, od = oracle_mod.rte_lw_gpt(tau, lay, inc, dec, emis, sfc, top_at_1=top_at_1, nmus=nmus, inc_flux=incf)
+    assert np.max(np.abs(fu - ou)) < FLUX_ATOL and np.max(np.abs(fd - od)) < FLUX_ATOL
+    bb = np.zeros((nlay + 1, ncol)); bbd = np.zeros((nlay + 1, ncol)); net = np.zeros((nlay + 1, ncol))
+    K.sum_broadband(I(ncol), I(nlay + 1), I(ng), P(fu), P(bb))
+    K.sum_broadband(I(ncol), I(nlay + 1), I(ng), P(fd), P(bbd))
+    obu, obd = oracle_mod.rte_lw(tau, lay, inc, dec, emis, sfc, top_at_1=top_at_1, nmus=nmus, inc_flux=incf)
+    assert np.max(np.abs(bb - obu)) < FLUX_ATOL and np.max(np.abs(bbd - obd)) < FLUX_ATOL
+    K.net_broadband_precalc(I(ncol), I(nlay + 1), P(bbd), P(bb), P(net))
+    assert np.array_equal(net, bbd - bb)
+    # ---- shortwave ----
+    tau = rng.uniform(0.001, 2.0, (ng, nlay, ncol)); ssa = rng.uniform(0, 0.999, (ng, nlay, ncol)); g = rng.uniform(0, 0.8, (ng, nlay, ncol))
+    mu0 = rng.uniform(0.1, 1.0, ncol); toa = rng.uniform(10, 100, (ng, ncol)); dif = rng.uniform(0, 5, (ng, ncol))
+    ad = rng.uniform(0.05, 0.4, (ng, ncol)); af = rng.uniform(0.05, 0.4, (ng, ncol))
+    fu = np.zeros((ng, nlay + 1, ncol)); fd = np.zeros((ng, nlay + 1, ncol)); fr = np.zeros((ng, nlay + 1, ncol))
+    fr[:, top, :] = toa * mu0[None, :]
+    fd[:, top, :] = dif
+    K.sw_solver_2stream(I(ncol), I(nlay), I(ng), B, P(tau), P(ssa), P(g), P(mu0), P(ad), P(af), P(fu), P(fd), P(fr))
+    ou, od, odir = oracle_mod.rte_sw_gpt(tau, ssa, g, mu0, toa, ad, af, top_at_1=top_at_1, inc_flux_dif=dif)
+    assert np.max(np.abs(fu - ou)) < FLUX_ATOL and np.max(np.abs(fd - od)) < FLUX_ATOL and np.max(np.abs(fr - odir)) < FLUX_ATOL
+    # device-pointer flavour of the same C entry points: the same bits as the host flavour
+    import torch
+    t = T(gpu)
+    dfu, dfd, dfr = (torch.zeros((ng, nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3))
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    keep = [t(x) for x in (tau, ssa, g, mu0, toa * mu0[None, :], dif, ad, af)]
+    rc = pkg.lib().ecckd_sw_solver_2stream_gpt(0, ncol, nlay, ng, int(top_at_1), *[vp(x) for x in keep], vp(dfu), vp(dfd), vp(dfr),
+                                               pkg.DEVICE, None)
+    assert rc == 0, pkg.last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(dfu.cpu().numpy(), fu) and np.array_equal(dfr.cpu().numpy(), fr)
