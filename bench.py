@@ -83,6 +83,23 @@ def committed_traffic(name, key):
         return None, "no committed PMC pass for this workload (%s)" % type(e).__name__
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X fp64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+                                   # (half the 157.3 TFLOP/s fp32 vector figure of MI355X_MICROARCH.md)
+
+
+def committed_counters(name, key, ncol):
+    """Per-launch PMC counters of kernel `key` from profiles/<name> (tools/pmc_summary.py), scaled from the column count
+    they were measured at to `ncol` -- only if the file was measured on THIS build of the kernels, else None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if tj.get("kernel_sha") != kernel_source_sha():
+            return None, "profiles/%s was measured on another build of the kernels (kernel_sha differs): not quoted" % name
+        f = ncol / float(tj["ncol"])
+        return {c: v * f for c, v in tj["kernels"][key].items()}, "profiles/%s (rocprofv3 --pmc, separate passes of this build)" % name
+    except Exception as e:
+        return None, "no committed PMC pass for this workload (%s)" % type(e).__name__
+
+
 def cpu_baseline(args, press_min):
     """The CPU restatement (oracle/, 'port' of the reference Fortran: same per-gas passes and temporaries as
     src/gas_optics_ecckd.f90:117-240,370 plus the RTE LW recurrences) timed on this host's cores over bounded
@@ -616,7 +633,29 @@ def main_sw(args):
              "rte_sw": 24.0 * cells + 8.0 * ncol * (ng + 3 + 2 * (nlay + 1))}
     kernels = {n: {"avg_ms": v, "alg_bytes_per_launch": alg_k.get(n), "GBps": alg_k[n] / (v * 1e-3) / 1e9 if n in alg_k and v > 0 else None}
                for n, v in kern.items()}
+    kern = {n: v for n, v in kern.items() if n in alg_k}
     dom = max(kern, key=kern.get)
+    # HBM roofline of the dominant kernel, and beside it the roofline of what actually binds rte_sw: fp64 vector
+    # arithmetic.  Counters (HBM bytes, fp64 instruction counts) come from the committed rocprofv3 --pmc passes of this build.
+    ctr, csrc = committed_counters("r02_pmc_sw.json", dom, ncol)
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (kernels[dom]["GBps"] or 0.0) / HBM_PEAK_GBS,
+                "traffic": ctr.get("hbm_bytes_per_launch") if ctr else None, "traffic_source": csrc,
+                "avg_launch_ms": kernels[dom]["avg_ms"], "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
+                "note": "rte_sw is bound by fp64 arithmetic (two exp, sqrt, three divisions per cell and pass), not by "
+                        "HBM: see roofline_fp64_valu and DESIGN.md 5.4"}
+    valu_roof = None
+    if ctr and "SQ_INSTS_VALU_FMA_F64" in ctr:
+        secs = kernels[dom]["avg_ms"] * 1e-3
+        flops = 64.0 * (2.0 * ctr["SQ_INSTS_VALU_FMA_F64"] + ctr.get("SQ_INSTS_VALU_MUL_F64", 0.0) + ctr.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                        + ctr.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        valu_roof = {"kernel": dom, "bound": "fp64-valu", "achieved": flops / secs / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "valu_instructions_per_cell": ctr.get("SQ_INSTS_VALU", 0.0) * 64.0 / cells if ctr.get("SQ_INSTS_VALU") else None,
+                     "valu_issue_frac_of_measured_peak": (ctr.get("SQ_INSTS_VALU", 0.0) / secs) / (256 * 0.86 * 2.4e9) if ctr.get("SQ_INSTS_VALU") else None,
+                     "note": "fp64 FMA (2 flop), MUL, ADD, transcendental wave-instructions x 64 lanes from SQ_INSTS_VALU_*_F64; "
+                             "measured sustained fp64 issue on this chip: 0.86 wave-instructions/clk/CU (tools/ubench.hip)",
+                     "source": csrc}
     # spot check against the CPU oracle
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
@@ -634,11 +673,8 @@ def main_sw(args):
         "unit": "Mcol*lay*gpt/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic %d columns x %d layers x %d g-points, SW wide-tol0.05, gas_optics + rte_sw "
-                               "two-stream, fp64 (BASELINE configs[2])" % (ncol, nlay, ng)},
-        "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (kernels[dom]["GBps"] or 0.0) / HBM_PEAK_GBS, "traffic": None,
-                     "note": "rte_sw is bound by fp64 arithmetic (two exp, sqrt, three divisions per cell and pass), "
-                             "not by HBM: DESIGN.md 5.4"},
+                               "two-stream, fp64 (BASELINE configs[2])" % (ncol, nlay, ng), "solver_options": pkg.solver_options()},
+        "roofline": roofline, "roofline_fp64_valu": valu_roof,
         "roofline_pipeline": {"bound": "hbm", "achieved": alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "kernels": kernels, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux, "cpu_baseline": None}), flush=True)

@@ -49,7 +49,10 @@ __device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
 // Planck source of one temperature for one g-point (calculate_planck_function, :275-288), table rows from
 // global memory (59 KB: L1/L2 resident).  tp0 = temperature_planck(1), rdt = 1/(temperature_planck(2)-(1)).
 struct PlanckTab { const double *tab; double t0, dt, rdt; int ntp, ng; };
-__device__ __forceinline__ double planck_at(const PlanckTab &P, double T, int g, double pi, double rpi) {
+// `tab` / `stride`: the table the rows are read from -- the model's (ng,ntp) table in global memory (stride ng), or the
+// block's copy in LDS whose rows are padded to an odd number of doubles: the 32 columns of a wave sit in different
+// (neighbouring) rows, and with a stride of 32 doubles they would all hit the same two banks.
+__device__ __forceinline__ double planck_at(const PlanckTab &P, const double *tab, int stride, double T, int g, double pi, double rpi) {
   double ti = (T - P.t0) * P.rdt;
   {   // exact quotient (Markstein) so that the row and the weights are the reference's
     const double rem = fma(-ti, P.dt, T - P.t0);
@@ -60,26 +63,43 @@ __device__ __forceinline__ double planck_at(const PlanckTab &P, double T, int g,
     ti = 1. + ti;
     const int it0 = ti >= (double)(P.ntp - 1) ? P.ntp - 1 : (int)ti;
     const double w1 = ti - it0, w0 = 1. - w1;
-    const double *r = P.tab + (long)(it0 - 1) * P.ng + g;
-    v = w0 * r[0] + w1 * r[P.ng];
+    const double *r = tab + (it0 - 1) * stride + g;
+    v = w0 * r[0] + w1 * r[stride];
   } else {
-    v = (T / P.t0) * P.tab[g];
+    v = (T / P.t0) * tab[g];
   }
   const double q = v * rpi;   // correctly rounded v / pi
   return fma(fma(-q, pi, v), rpi, q);
 }
 
+// NG tile groups of NW waves per block.  The Planck-recomputing form runs two groups per block (8 waves) that share one
+// copy of the Planck table in LDS (61-68 KB): read from global memory instead, the two dependent table loads per source
+// leave the kernel latency-bound at its two waves per SIMD (measured 21 ms per 1e6 columns against 11 from LDS).
+constexpr int split_groups(bool planck) { return planck ? 2 : 1; }
+__host__ __device__ constexpr int planck_stride(int ng) { return ng | 1; }   // odd number of doubles per row
+
 template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK, int WPS>
-__global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwArgs a, const PlanckTab pt,
+__global__ void __launch_bounds__(64 * NW * split_groups(PLANCK), WPS) rte_lw_split_kernel(const RteLwArgs a, const PlanckTab pt,
                                                                                           const double *tlay, const double *tlev,
                                                                                           const double *tsfc) {
   constexpr int GW = 64 / CW;
   constexpr int NL = SEG * NW;
+  constexpr int NG = split_groups(PLANCK);
+  constexpr int kGroupDoubles = 2 * (NL + 1) * CW + 2 * NW * 3 * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  double *acc_dn = reinterpret_cast<double *>(lds_raw);          // [NL+1][CW]
-  double *acc_up = acc_dn + (NL + 1) * CW;                        // [NL+1][CW]
-  double *xch = acc_up + (NL + 1) * CW;                           // [2][NW][3][64]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = (tid >> 6) / NW, w = (tid >> 6) % NW, gtid = tid - grp * 64 * NW;
+  double *acc_dn = reinterpret_cast<double *>(lds_raw) + grp * kGroupDoubles;   // [NL+1][CW]
+  double *acc_up = acc_dn + (NL + 1) * CW;                                         // [NL+1][CW]
+  double *xch = acc_up + (NL + 1) * CW;                                            // [2][NW][3][64]
+  [[maybe_unused]] const int pstride = PLANCK ? planck_stride(a.ng) : 0;
+  [[maybe_unused]] double *ptab = reinterpret_cast<double *>(lds_raw) + NG * kGroupDoubles;   // PLANCK: [ntp][pstride]
+  if (PLANCK) {
+    for (int i = tid; i < pt.ntp * pt.ng; i += 64 * NW * NG) {
+      const int r = i / pt.ng, g = i - r * pt.ng;
+      ptab[r * pstride + g] = pt.tab[i];
+    }
+  }
   const int cl = lane % CW, gs = lane / CW;
   const bool owner = gs == 0;
   const int ncol = a.ncol, ng = a.ng;
@@ -95,10 +115,13 @@ __global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwA
   const long ntiles = ((long)ncol + CW - 1) / CW;
   const int s0 = w * SEG;   // first layer of this wave, in walking order from the top
 
-  for (int i = tid; i < 2 * (NL + 1) * CW; i += 64 * NW) acc_dn[i] = 0.;
+  for (int i = gtid; i < 2 * (NL + 1) * CW; i += 64 * NW) acc_dn[i] = 0.;
   __syncthreads();
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // every group of the block walks the same number of tiles (block barriers inside): a group whose tile lies beyond the
+  // end computes on clamped columns and stores nothing
+  for (long tile0 = (long)blockIdx.x * NG; tile0 < ntiles; tile0 += (long)gridDim.x * NG) {
+    const long tile = tile0 + grp;
     const long col = tile * CW + cl;
     const bool valid = col < ncol;
     const long cc = valid ? col : (long)ncol - 1;
@@ -154,14 +177,14 @@ __global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwA
       // ---------------- phase 1: this wave's SEG layers ----------------
       double T[SEG], SDN[SEG], SU[SEG];
       double Tq = 1., Dq = 0.;
-      [[maybe_unused]] double carry = PLANCK ? planck_at(pt, near_first, gg, pi_f32, rpi_f32) : near_first;
+      [[maybe_unused]] double carry = PLANCK ? planck_at(pt, ptab, pstride, near_first, gg, pi_f32, rpi_f32) : near_first;
 #pragma unroll
       for (int s = 0; s < SEG; ++s) {
         const double tau = ptau[s % kSplitPF];
         double lay, bdn, bup;
         if (PLANCK) {
-          lay = planck_at(pt, ptl[s % kSplitPF], gg, pi_f32, rpi_f32);
-          bdn = planck_at(pt, ptv[s % kSplitPF], gg, pi_f32, rpi_f32);
+          lay = planck_at(pt, ptab, pstride, ptl[s % kSplitPF], gg, pi_f32, rpi_f32);
+          bdn = planck_at(pt, ptab, pstride, ptv[s % kSplitPF], gg, pi_f32, rpi_f32);
           bup = carry;
         } else {
           lay = play_[s % kSplitPF];
@@ -214,7 +237,7 @@ __global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwA
         I = x[(q * 3 + 0) * 64 + lane] * I + x[(q * 3 + 1) * 64 + lane];
       }
       const double eps = a.sfc_emis[a.gpt2band[gg] + (long)a.nband * cc];
-      const double sfc_src = PLANCK ? planck_at(pt, tsfc[cc], gg, pi_f32, rpi_f32) : a.sfc_source[cc + (long)ncol * gg];
+      const double sfc_src = PLANCK ? planck_at(pt, ptab, pstride, tsfc[cc], gg, pi_f32, rpi_f32) : a.sfc_source[cc + (long)ncol * gg];
       double U = I * (1. - eps) + eps * sfc_src;   // surface
       double Uin = U;
 #pragma unroll
@@ -242,7 +265,7 @@ __global__ void __launch_bounds__(64 * NW, WPS) rte_lw_split_kernel(const RteLwA
 
     // broadband fluxes of the tile: level s-th from the top -> lev0 + lstep*s
     __syncthreads();
-    for (int i = tid; i < (NL + 1) * CW; i += 64 * NW) {
+    for (int i = gtid; i < (NL + 1) * CW; i += 64 * NW) {
       const int s = i / CW, c = i - s * CW;
       const long cg = tile * CW + c;
       if (cg < ncol) {
@@ -261,13 +284,16 @@ template <int SEG, int NW, int CW, bool SHARED, bool SER3, bool PLANCK, int WPS 
 hipError_t launch_split(const RteLwArgs &a, const PlanckTab &pt, const double *tlay, const double *tlev, const double *tsfc,
                         hipStream_t s) {
   auto k = rte_lw_split_kernel<SEG, NW, CW, SHARED, SER3, PLANCK, WPS>;
-  const size_t lds = sizeof(double) * (2 * (size_t)(SEG * NW + 1) * CW + 2 * NW * 3 * 64);
+  constexpr int NG = split_groups(PLANCK);
+  const size_t lds = sizeof(double) * (NG * (2 * (size_t)(SEG * NW + 1) * CW + 2 * NW * 3 * 64) +
+                                       (PLANCK ? (size_t)pt.ntp * planck_stride(a.ng) : 0));
+  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  long tiles = ((long)a.ncol + CW - 1) / CW;
-  const long cap = 256L * WPS * 4;   // four rounds of resident blocks; the rest by grid stride
-  if (tiles > cap) tiles = cap;
-  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64 * NW), lds, s, a, pt, tlay, tlev, tsfc);
+  long blocks = (((long)a.ncol + CW - 1) / CW + NG - 1) / NG;
+  const long cap = PLANCK ? 256L * 4 : 256L * WPS * 4;   // four rounds of resident blocks; the rest by grid stride
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * NW * NG), lds, s, a, pt, tlay, tlev, tsfc);
   return hipGetLastError();
 }
 
