@@ -9,6 +9,7 @@ tag=$1
 export TMPDIR=/tmp
 o=gpurun_out
 P="--cpu-seconds 0 --no-side"
+if [ "$2" != "extra" ]; then
 python bench.py --steps 10 --warmup 2 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -- python3 bench.py --steps 3 --warmup 1 $P > $o/${tag}_bench_prof.json 2> $o/${tag}_bench_prof.err
@@ -31,6 +32,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $o/${tag}_pmcsw_sq2 -- python3 bench.py $S --steps 2 --warmup 1 --cpu-seconds 0 > /dev/null 2> $o/${tag}_pmcsw_sq2.err
 python tools/pmc_summary.py "synthetic 100000 columns x 60 layers x 27 g-points, SW wide-tol0.05, fp64" 100000 $o/${tag}_pmcsw_FETCH_SIZE $o/${tag}_pmcsw_WRITE_SIZE $o/${tag}_pmcsw_sq1 $o/${tag}_pmcsw_sq2 > $o/${tag}_pmc_sw.json
 echo "sw passes done"
+fi
 if [ "$2" != "quick" ]; then
   # ---- memory-side stall counters: ONE counter per pass (the *_sum metrics expand to one hardware counter per TCC
   # channel / TCP instance: several of them in a pass is what rocprofv3 refused in round 1), bounded by timeout ----
