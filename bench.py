@@ -279,6 +279,10 @@ def main():
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling passes)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the process group is gloo "
+                         "(RCCL cannot put two ranks on one device).  Exercises the rank/column-range/barrier/MAX/gather "
+                         "logic; the number it prints is NOT a scaling measurement and says so.")
     ap.add_argument("--fortran-sample", type=int, default=200000,
                     help="columns of the side measurement through the Fortran type-bound API in device-resident mode "
                          "(ecckd_driver: host arrays in, fluxes out, tau and sources stay in HBM; 0 = skip)")
@@ -301,13 +305,19 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or "RANK" in os.environ   # launched through torch.distributed.run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cpu_coll = distributed and args.rehearse_on_one_gpu   # gloo: collectives on host tensors
 
     lw_file = LW_FILE if args.lut == "fsck" else LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061")
     L = pkg.lib()
@@ -330,7 +340,10 @@ def main():
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            if cpu_coll:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
         step()
@@ -352,10 +365,11 @@ def main():
 
     rank_ms = [t_rank / args.steps * 1e3]
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if cpu_coll else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([t_rank / args.steps * 1e3], dtype=torch.float64, device=dev)
+        mine = torch.tensor([t_rank / args.steps * 1e3], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_ms = [float(x.item()) for x in allr]
@@ -412,7 +426,8 @@ def main():
             "config": {"workload": ("synthetic %d columns x %d layers x %d g-points per GPU, LW " % (ncol, nlay, ng)) + os.path.basename(lw_file)[36:-3] + ", "
                                    "gas_optics + rte_lw (1 angle), " + ("fp64" if args.dtype == "f64" else "fp32") + ", inputs and intermediates HBM-resident; " + what,
                        "ncol_per_gpu": ncol, "ncol_total": ncol * world, "nlay": nlay, "ngpt": ng,
-                       "parallelism": "column-range x%d, no collective" % world,
+                       "parallelism": "column-range x%d, no collective" % world + (
+                           " -- REHEARSAL: all ranks on one GPU over gloo, not a scaling measurement" if args.rehearse_on_one_gpu else ""),
                        "arithmetic": args.arithmetic, "solver_options": pkg.solver_options()},
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms},
             "roofline": roofline,

@@ -46,6 +46,7 @@ struct TauArgs {
   // launch geometry chosen by the host
   int R;                       // pressure rows of the LDS slab
   int col_chunks;              // grid.x; each block walks tiles chunk by chunk
+  int seg;                     // fused kernel: tiles per segment (slab-range pre-pass + barriers once per segment)
 };
 
 // Division by a wave-uniform constant, d with its reciprocal (kernels_gas_fused.hip: udiv()).

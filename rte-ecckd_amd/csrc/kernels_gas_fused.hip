@@ -39,7 +39,17 @@ namespace {
 #endif
 constexpr int kBlock = ECCKD_FUSED_BLOCK;
 constexpr int kWaves = kBlock / 64;
-constexpr int kSeg = 8;    // tiles between two slab-range checks (block barriers)
+#ifndef ECCKD_FUSED_SEG
+#define ECCKD_FUSED_SEG 8
+#endif
+#ifndef ECCKD_FUSED_SEG_MAX
+#define ECCKD_FUSED_SEG_MAX 64
+#endif
+// Tiles between two slab-range checks (pre-pass + block barriers).  kSeg sizes the grid (enough blocks for small
+// column counts); the segment a block actually walks is TauArgs::seg = its whole tile range up to kSegMax -- measured at
+// 1e6 columns: 4 / 8 / 16 / 32 tiles per segment = 13.51 / 13.27 / 13.06 / 12.92 ms.
+constexpr int kSeg = ECCKD_FUSED_SEG;
+constexpr int kSegMax = ECCKD_FUSED_SEG_MAX;
 
 // Compile-time loop: f(integral_constant<int, I>) for I = I0 .. N-1, as straight-line code.  The
 // item pipeline below must be fully unrolled (its buffer indices and item kinds are static);
@@ -255,8 +265,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   const real *plev0 = P(t.plev) + (long)ncol * j, *plev1 = P(t.plev) + (long)ncol * (j + 1);
   const real pi = (real)3.14159265359f, rpi = real(1) / pi;   // :53
 
-  for (long seg = t_begin; seg < t_end; seg += kSeg) {
-    const long seg_end = seg + kSeg < t_end ? seg + kSeg : t_end;
+  const int seg_len = t.seg;
+  for (long seg = t_begin; seg < t_end; seg += seg_len) {
+    const long seg_end = seg + seg_len < t_end ? seg + seg_len : t_end;
     // ---- pre-pass: range of p0+p1 over the segment; the pressure index is monotone in it ----
     // ... and, when only a window of the Planck table is staged, the range of the temperatures that
     // index it (layer j and its two levels); the table row is monotone in T.
@@ -910,6 +921,10 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   if (chunks * kSeg > ntiles) chunks = (ntiles + kSeg - 1) / kSeg;
   if (chunks < 1) chunks = 1;
   t.col_chunks = (int)chunks;
+  {
+    long per_block = (ntiles + chunks - 1) / chunks;
+    t.seg = (int)(per_block < kSeg ? kSeg : (per_block > kSegMax ? kSegMax : per_block));
+  }
   if (a.f32 && a.mode != MODE_LW) return hipErrorNotSupported;   // single precision: the longwave fused path only
   plan.lds_bytes = lds;
   plan.anyclamp = anyclamp ? 1 : 0;

@@ -32,7 +32,11 @@ namespace {
 #ifndef ECCKD_SPLIT_WAVES_PER_SIMD
 #define ECCKD_SPLIT_WAVES_PER_SIMD 3
 #endif
-constexpr int kSplitPF = ECCKD_SPLIT_PF;   // layers in flight per lane
+#ifndef ECCKD_SPLIT_PF_PLANCK
+#define ECCKD_SPLIT_PF_PLANCK 2
+#endif
+// layers in flight per lane
+constexpr int split_pf(bool planck) { return planck ? ECCKD_SPLIT_PF_PLANCK : ECCKD_SPLIT_PF; }
 
 template <int CW>
 __device__ __forceinline__ double gsum(double v) {
@@ -85,6 +89,7 @@ __global__ void __launch_bounds__(64 * NW * split_groups(PLANCK), WPS) rte_lw_sp
   constexpr int GW = 64 / CW;
   constexpr int NL = SEG * NW;
   constexpr int NG = split_groups(PLANCK);
+  constexpr int kSplitPF = split_pf(PLANCK);
   constexpr int kGroupDoubles = 2 * (NL + 1) * CW + 2 * NW * 3 * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63;

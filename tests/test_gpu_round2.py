@@ -653,3 +653,34 @@ def test_rte_kernel_level_interfaces(pkg, gpu, oracle_mod, top_at_1, nmus):
     assert rc == 0, pkg.last_error()
     torch.cuda.synchronize()
     assert np.array_equal(dfu.cpu().numpy(), fu) and np.array_equal(dfr.cpu().numpy(), fr)
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-rank rehearsal of bench.py on one GPU
+# ------------------------------------------------------------------------------------------------
+def test_bench_two_ranks_rehearsal(pkg, gpu, tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here
+    with 2 ranks that both sit on cuda:0 over gloo (--rehearse-on-one-gpu: RCCL cannot put two ranks on one device):
+    the product library is loaded and driven by every rank, rank r generates columns [r*ncol, (r+1)*ncol), the timed
+    region is bracketed by barriers, the elapsed time is the MAX over ranks, every rank's own time is gathered, and
+    rank 0 prints ONE JSON line whose value is the whole-job throughput."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ncol", "60000",
+           "--cpu-seconds", "0", "--no-side", "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ncol_per_gpu"] == 60000 and d["config"]["ncol_total"] == 120000
+    assert len(d["per_rank_ms_per_step"]["ranks"]) == 2
+    assert d["per_rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001 + 1e-3
+    assert abs(d["value"] - 2 * 60000 * 60 * 32 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL and "REHEARSAL" in d["config"]["parallelism"]
+    assert d["roofline"]["kernel"] in ("gas_lw_fused", "rte_lw") and d["cpu_baseline"] is None

@@ -16,7 +16,7 @@ for rep in range(2):
     for lib in libs:
         env = dict(os.environ, ECCKD_LIB=lib)
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ncol", ncol, "--steps", "5",
-                              "--warmup", "2", "--cpu-seconds", "0", "--mode", mode, "--dtype", dtype], env=env, capture_output=True, text=True)
+                              "--warmup", "2", "--cpu-seconds", "0", "--mode", mode, "--dtype", dtype] + (["--no-side"] if mode == "lw" else []), env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
             kk = d["kernels"] if "kernels" in d else {k: {"avg_ms": v} for k, v in d["kernels_avg_ms"].items()}
