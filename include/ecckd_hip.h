@@ -248,8 +248,10 @@ int ecckd_sum_broadband(int device, int ncol, int nlev, int ngpt, const double *
  * Planck table (src/gas_optics_ecckd.f90:407-424), so a host that only needs fluxes does not have to move them:
  * gas optics writes tau only (8 B/cell) and the solver recomputes the sources while it reads tau (8 B/cell) --
  * 16 instead of 64 B per (column, layer, g-point) between the two kernels.  Same arithmetic per cell (sources bit
- * identical to ecckd_gas_optics_lw); fast arithmetic mode, fp64, 60 layers.  This path is bound by fp64 issue, not by
- * HBM, and bench.py reports it apart from the API-boundary roofline ("fused_lw").
+ * identical to ecckd_gas_optics_lw); fast arithmetic mode, fp64.  60 layers take the fused kernels; any other layer
+ * count is served by the general route (Planck kernel into library scratch, then the register-resident solver): the same
+ * results at the API path's rate.  This path is bound by fp64 issue, not by HBM, and bench.py reports it apart from the
+ * API-boundary roofline ("fused_lw").
  *   ecckd_gas_optics_lw_tau  gas_optical_depth (:323-376) alone: tau(ncol,nlay,ngpt)              ECCKD_DEVICE
  *   ecckd_rte_lw_fused       rte_lw on tau + temperatures; sfc_emis(nband,ncol), inc_flux(ncol,ngpt) or NULL  ECCKD_DEVICE
  *   ecckd_lw_fluxes          both, tau in library-owned stream-ordered scratch      ECCKD_DEVICE or ECCKD_HOST

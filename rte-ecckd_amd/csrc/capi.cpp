@@ -65,14 +65,16 @@ Arena g_solver_arena[16];
 // block that belongs to (device, stream).  Work on one stream is ordered, so consecutive calls on a stream
 // reuse its block without any synchronisation, and calls on different streams never share one -- the call
 // stays asynchronous and can be captured in a HIP graph.  A block that has become too small is retired, not
-// freed (a kernel in flight or a captured graph may still hold its address) and a larger one is allocated;
-// retired blocks are released by ecckd_release_scratch() or when the process ends.  A caller that wants no
+// freed while a kernel in flight or a captured graph may still hold its address (it is freed at once when the stream
+// has drained and nothing was ever captured) and a larger one is allocated; retired blocks are released by
+// ecckd_release_scratch() or when the process ends.  A caller that wants no
 // allocation inside the library at all hands its own buffer over with ecckd_set_stream_scratch().
 struct ScratchPool {
   std::mutex mu;
-  struct Block { void *p = nullptr; size_t bytes = 0; bool caller_owned = false; };
+  struct Block { void *p = nullptr; size_t bytes = 0; bool caller_owned = false; };   // (a block handed to a captured call is never reused: see stream_scratch)
   std::map<hipStream_t, Block> live;
   std::vector<void *> retired;
+  bool any_capture = false;   // a call was captured into a graph with a block of this pool: outgrown blocks are kept
 };
 ScratchPool g_scratch_pool[16];
 
@@ -81,12 +83,18 @@ int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
   ScratchPool &pool = g_scratch_pool[device];
   std::lock_guard<std::mutex> lock(pool.mu);
   ScratchPool::Block &b = pool.live[stream];
-  if (b.bytes >= need) { *out = b.p; return 0; }
+  if (b.bytes >= need) {
+    hipStreamCaptureStatus c0 = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &c0) == hipSuccess && c0 != hipStreamCaptureStatusNone) pool.any_capture = true;
+    *out = b.p;
+    return 0;
+  }
   if (b.caller_owned)
     return fail("ecckd: the scratch buffer set with ecckd_set_stream_scratch is too small for this call (" +
                 std::to_string(need) + " bytes needed: ecckd_rte_lw_scratch_bytes / ecckd_rte_sw_scratch_bytes)");
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if (capturing)
     return fail("ecckd: this call needs " + std::to_string(need) + " bytes of solver scratch on a stream that is being "
                 "captured; run the call once on this stream before the capture, or hand a buffer over with "
                 "ecckd_set_stream_scratch (no allocation happens inside a capture)");
@@ -96,7 +104,12 @@ int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
     want = need;
     HIPCHK(hipMalloc(&p, want));
   }
-  if (b.p) pool.retired.push_back(b.p);
+  if (b.p) {
+    // The outgrown block: free it now if nothing can still refer to it -- the stream has drained and no graph was
+    // captured on this device (a captured graph holds scratch addresses for as long as it lives); else retire it.
+    if (!pool.any_capture && hipStreamQuery(stream) == hipSuccess) (void)hipFree(b.p);
+    else pool.retired.push_back(b.p);
+  }
   b.p = p; b.bytes = want; b.caller_owned = false;
   *out = p;
   return 0;
@@ -1302,10 +1315,18 @@ int ecckd_gas_optics_lw_tau(const ecckd_model_t *m, int ncol, int nlay, const do
                                static_cast<hipStream_t>(stream));
 }
 
+// Scratch (in doubles) the fused solver needs besides tau: none at 60 layers (the Planck sources are recomputed inside the
+// layer-split solver); any other layer count takes the general route -- Planck kernel into scratch, then the
+// register-resident solver with shared level sources -- and needs room for the sources and that solver's ring.
+static size_t fused_scratch_doubles(const ecckd_model *m, int ncol, int nlay) {
+  if (nlay == 60) return 0;
+  const size_t n3 = (size_t)ncol * nlay * m->ng;
+  return 3 * n3 + (size_t)ncol * m->ng + 32 + ecckd::rte_lw_scratch_bytes(ncol, nlay, m->ng) / sizeof(double);
+}
+
 static int rte_lw_fused_dev(const ecckd_model *m, int ncol, int nlay, int top_at_1, int n_gauss_angles, const double *tau,
                             const double *tlay, const double *tlev, const double *tsfc, const double *sfc_emis,
-                            const double *inc_flux, double *flux_up, double *flux_dn, hipStream_t stream) {
-  if (nlay != 60) return fail("ecckd: the fused longwave solver is implemented for 60 layers (use gas_optics + rte_lw)");
+                            const double *inc_flux, double *flux_up, double *flux_dn, double *scratch, hipStream_t stream) {
   ecckd::RteLwArgs a{};
   if (fill_band_map(m->ng, m->nband, m->band2gpt.data(), a.gpt2band)) return 1;
   a.ncol = ncol; a.nlay = nlay; a.ng = m->ng; a.top_at_1 = top_at_1 ? 1 : 0; a.nmus = n_gauss_angles;
@@ -1323,9 +1344,33 @@ static int rte_lw_fused_dev(const ecckd_model *m, int ncol, int nlay, int top_at
     a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
   }
   a.tau = tau; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux; a.flux_up = flux_up; a.flux_dn = flux_dn;
-  ProfScope prof("rte_lw_fused", stream);
-  HIPCHK(ecckd::launch_rte_lw_planck(a, m->dbuf + m->off_planck, m->ntp, m->temperature_planck[0],
-                                     m->temperature_planck[1] - m->temperature_planck[0], tlay, tlev, tsfc, stream));
+  if (nlay == 60) {
+    ProfScope prof("rte_lw_fused", stream);
+    HIPCHK(ecckd::launch_rte_lw_planck(a, m->dbuf + m->off_planck, m->ntp, m->temperature_planck[0],
+                                       m->temperature_planck[1] - m->temperature_planck[0], tlay, tlev, tsfc, stream));
+    return 0;
+  }
+  // general route (any layer count): sources through scratch, one value per level
+  if (!scratch) return fail("ecckd: internal: the fused longwave solver needs scratch for this layer count");
+  const size_t n3 = (size_t)ncol * nlay * m->ng;
+  double *lay = scratch, *inc = lay + n3, *dec = inc + n3, *sfc = dec + n3, *ring = sfc + (((size_t)ncol * m->ng + 31) & ~(size_t)31);
+  ecckd::PlanckArgs p{};
+  p.ncol = ncol; p.nlay = nlay; p.ng = m->ng; p.ntp = m->ntp;
+  p.planck = m->dbuf + m->off_planck;
+  p.t0 = m->temperature_planck[0];
+  p.dt = m->temperature_planck[1] - m->temperature_planck[0];
+  p.tlay = tlay; p.tlev = tlev; p.tsfc = tsfc;
+  p.lay_source = lay; p.lev_source_inc = inc; p.lev_source_dec = dec; p.sfc_source = sfc;
+  {
+    ProfScope prof("planck", stream);
+    HIPCHK(ecckd::launch_planck(p, stream));
+  }
+  a.lay_source = lay; a.lev_source_inc = inc; a.lev_source_dec = dec; a.sfc_source = sfc;
+  a.shared_levels = inc_flux ? 0 : 1;
+  a.use_split = 0;
+  a.scratch = ecckd::rte_lw_scratch_bytes(ncol, nlay, m->ng) ? ring : nullptr;
+  ProfScope prof("rte_lw", stream);
+  HIPCHK(ecckd::launch_rte_lw(a, stream));
   return 0;
 }
 
@@ -1340,8 +1385,12 @@ int ecckd_rte_lw_fused(const ecckd_model_t *m, int ncol, int nlay, int top_at_1,
   if (!tlev) return fail("tlev is required for ecckd");
   HIPCHK(hipSetDevice(m->device));
   if (ncol == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  void *sp = nullptr;
+  const size_t extra = fused_scratch_doubles(m, ncol, nlay);
+  if (extra && stream_scratch(m->device, st, extra * sizeof(double), &sp)) return 1;
   return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,
-                          flux_dn, static_cast<hipStream_t>(stream));
+                          flux_dn, static_cast<double *>(sp), st);
 }
 
 int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *plev, const double *tlay, const double *tsfc,
@@ -1362,18 +1411,20 @@ int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *pl
   if (memspace == ECCKD_DEVICE) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     void *tau_p = nullptr;   // tau lives in the stream's scratch block between the two kernels
-    if (stream_scratch(m->device, st, n3 * sizeof(double), &tau_p)) return 1;
+    const size_t extra = fused_scratch_doubles(m, ncol, nlay);
+    if (stream_scratch(m->device, st, (n3 + 32 + extra) * sizeof(double), &tau_p)) return 1;
     double *d_tau = static_cast<double *>(tau_p);
     if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, d_tau, false, nullptr, nullptr, nullptr, nullptr, st)) return 1;
     return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, d_tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,
-                            flux_dn, st);
+                            flux_dn, extra ? d_tau + ((n3 + 31) & ~(size_t)31) : nullptr, st);
   }
   if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
   ecckd_model *mm = const_cast<ecckd_model *>(m);
   std::lock_guard<std::mutex> lock(mm->mu);
   hipStream_t s = mm->host_stream;
   const size_t need = align256(n2l * 8) * 4 + align256(n2 * 8) + align256((size_t)ncol * 8) + staged_gas_bytes(gd, ncol, nlay) +
-                      align256((size_t)ncol * m->nband * 8) + align256((size_t)ncol * m->ng * 8) + align256(n3 * 8);
+                      align256((size_t)ncol * m->nband * 8) + align256((size_t)ncol * m->ng * 8) + align256(n3 * 8) +
+                      align256(fused_scratch_doubles(m, ncol, nlay) * 8);
   if (need > mm->arena_bytes) {
     HIPCHK(hipStreamSynchronize(s));
     if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
@@ -1390,9 +1441,11 @@ int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *pl
   StagedGases sg;
   if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
   double *d_tau = b.take(n3);
+  const size_t extra = fused_scratch_doubles(m, ncol, nlay);
+  double *d_extra = extra ? b.take(extra) : nullptr;
   if (gas_optical_depth_dev(m, ncol, nlay, d_plev, d_tlay, sg.gd, d_tau, false, nullptr, nullptr, nullptr, nullptr, s)) return 1;
   if (rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, d_tau, d_tlay, d_tlev, d_tsfc, d_emis, inc_flux ? d_incf : nullptr,
-                       d_up, d_dn, s))
+                       d_up, d_dn, d_extra, s))
     return 1;
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));

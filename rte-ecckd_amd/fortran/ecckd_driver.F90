@@ -2,11 +2,12 @@
 ! example/rfmip-rad-irf/ecckd_rfmip_lw.F90:107-136 and ecckd_rfmip_sw.F90:112-162: load the ecCKD
 ! file, then per column block gas_optics() followed by rte_lw()/rte_sw(), fluxes out.
 !
-!   ecckd_driver lw|sw  <ecckd_file.nc>  <input.bin>  <output.bin>  [block_size] [n_quad_angles] [device_resident 0|1] [repeats] [byband 0|1]
+!   ecckd_driver lw|sw  <ecckd_file.nc>  <input.bin>  <output.bin>  [block_size] [n_quad_angles] [device_resident 0|1] [repeats] [byband 0|1] [fused 0|1]
 !
 ! device_resident = 1: optical_props / source are the device twins of mo_ecckd_device (tau and the sources stay in
 ! HBM between gas_optics and the solver; ECCKD_MIXED memory space of the C ABI).
 ! repeats: the block loop is run that many times and the best wall time is printed ("loop_seconds", bench.py reads it).
+! fused = 1 (lw): one call ecckd%lw_fluxes(...) per block instead of gas_optics + rte_lw (the library's fused longwave path).
 ! byband = 1: fluxes go through ty_fluxes_byband (per-band arrays; their sum over bands must reproduce the broadband
 ! fluxes, which are what output.bin holds either way).
 !
@@ -32,7 +33,7 @@ program ecckd_driver
   integer(int32) :: ncol, nlay, ngas
   integer :: block_size, n_quad_angles, nblocks, b, c0, c1, nc, i, ibnd, nbnd, u, dev_flag, repeats, rep, byband
   integer(kind=8) :: t0, t1, rate
-  integer :: nc_alloc = -1
+  integer :: nc_alloc = -1, fused = 0
   real(wp) :: best, secs
   real(wp), dimension(:,:,:), allocatable, target :: bnd_up, bnd_dn
   logical :: top_at_1, lw
@@ -83,6 +84,10 @@ program ecckd_driver
   if (command_argument_count() >= 9) then
     call get_command_argument(9, arg)
     read(arg, *) byband
+  end if
+  if (command_argument_count() >= 10) then
+    call get_command_argument(10, arg)
+    read(arg, *) fused
   end if
   if (byband /= 0) then
     fluxes => fluxes_band
@@ -161,7 +166,10 @@ program ecckd_driver
         sfc_spec(ibnd, i) = bc1(c0 + i - 1)
       end do
     end do
-    if (lw) then
+    if (lw .and. fused /= 0) then
+      call stop_on_err(ecckd%lw_fluxes(plev(c0:c1, :), tlay(c0:c1, :), tsfc(c0:c1), tlev(c0:c1, :), gas_concs(b), top_at_1, &
+                                       sfc_spec, flux_up(c0:c1, :), flux_dn(c0:c1, :), n_gauss_angles=n_quad_angles))
+    else if (lw) then
       if (nc /= nc_alloc) then                                 ! (the reference allocates once, before its loop: :102-103)
         call stop_on_err(source%alloc(nc, nlay, ecckd))
         call stop_on_err(op1%alloc_1scl(nc, nlay, ecckd))

@@ -52,6 +52,7 @@ module gas_optics_ecckd
     procedure, public :: get_temp_max
     procedure, public :: gas_optics_int
     procedure, public :: gas_optics_ext
+    procedure, public :: lw_fluxes          !< extension: gas_optics + rte_lw in one call (fused longwave path)
   end type ty_gas_optics_ecckd
 
   interface
@@ -165,6 +166,21 @@ module gas_optics_ecckd
       type(c_ptr), value :: stream
       integer(c_int) :: rc
     end function c_gas_optics_sw
+    function c_lw_fluxes(model, ncol, nlay, plev, tlay, tsfc, tlev, ngas, gas_names, vmr, cs, ls, scalar, top_at_1, nmus, &
+                         sfc_emis, inc_flux, flux_up, flux_dn, memspace, stream) bind(C, name="ecckd_lw_fluxes") result(rc)
+      import c_ptr, c_int, c_double, c_char, c_long_long
+      type(c_ptr), value :: model
+      integer(c_int), value :: ncol, nlay, ngas, top_at_1, nmus, memspace
+      real(c_double), dimension(*), intent(in) :: plev, tlay, tsfc, tlev, sfc_emis
+      character(kind=c_char), dimension(*), intent(in) :: gas_names
+      type(c_ptr), dimension(*), intent(in) :: vmr
+      integer(c_long_long), dimension(*), intent(in) :: cs, ls
+      real(c_double), dimension(*), intent(in) :: scalar
+      type(c_ptr), value :: inc_flux
+      real(c_double), dimension(*), intent(inout) :: flux_up, flux_dn
+      type(c_ptr), value :: stream
+      integer(c_int) :: rc
+    end function c_lw_fluxes
   end interface
 
   public :: c_error_message, c_loc_3d, c_loc_2d
@@ -468,6 +484,51 @@ contains
                          ptr, cs, ls, scalar, tau_p, ssa_p, g_p, toa_src, memspace, c_null_ptr)
     if (rc /= 0) error_msg = c_error_message()
   end function gas_optics_ext
+
+  !> Extension (no counterpart in the reference): broadband longwave fluxes in one call -- what the reference's block
+  !! loop computes with ecckd%gas_optics(...) followed by rte_lw(...) (ecckd_rfmip_lw.F90:120-135) -- through the fused
+  !! path of the library (ecckd_lw_fluxes: tau stays on the GPU, the Planck sources are recomputed inside the solver).
+  !! Host arrays in, host fluxes out (60 layers take the fused kernels, other counts the general route).  flux_up / flux_dn are (ncol, nlay+1), sfc_emis (nband, ncol).
+  function lw_fluxes(this, plev, tlay, tsfc, tlev, gas_desc, top_at_1, sfc_emis, flux_up, flux_dn, n_gauss_angles) &
+      result(error_msg)
+    class(ty_gas_optics_ecckd), intent(in) :: this
+    real(wp), dimension(:,:), intent(in) :: plev, tlay, tlev
+    real(wp), dimension(:), intent(in) :: tsfc
+    type(ty_gas_concs), intent(in) :: gas_desc
+    logical, intent(in) :: top_at_1
+    real(wp), dimension(:,:), intent(in) :: sfc_emis
+    real(wp), dimension(:,:), intent(inout) :: flux_up, flux_dn
+    integer, intent(in), optional :: n_gauss_angles
+    character(len=128) :: error_msg
+    character(kind=c_char), dimension(:), allocatable :: names
+    type(c_ptr), dimension(:), allocatable :: ptr
+    integer(c_long_long), dimension(:), allocatable :: cs, ls
+    real(c_double), dimension(:), allocatable :: scalar
+    real(wp), dimension(:,:), allocatable :: up, dn
+    integer :: ncol, nlay, n, nmus
+    integer(c_int) :: rc
+    ncol = size(tlay, 1)
+    nlay = size(tlay, 2)
+    nmus = 1
+    if (present(n_gauss_angles)) nmus = n_gauss_angles
+    error_msg = marshal_gases(this, gas_desc, ncol, nlay, names, ptr, cs, ls, scalar)
+    if (trim(error_msg) /= "") return
+    if (size(sfc_emis, 1) /= this%get_nband() .or. size(sfc_emis, 2) /= ncol) then
+      error_msg = "lw_fluxes: sfc_emis inconsistently sized"
+      return
+    end if
+    n = gas_desc%get_num_gases()
+    allocate(up(ncol, nlay + 1), dn(ncol, nlay + 1))
+    rc = c_lw_fluxes(this%handle, int(ncol, c_int), int(nlay, c_int), plev, tlay, tsfc, tlev, int(n, c_int), names, ptr, cs, &
+                     ls, scalar, merge(1_c_int, 0_c_int, top_at_1), int(nmus, c_int), sfc_emis, c_null_ptr, up, dn, &
+                     ECCKD_HOST, c_null_ptr)
+    if (rc /= 0) then
+      error_msg = c_error_message()
+      return
+    end if
+    flux_up = up
+    flux_dn = dn
+  end function lw_fluxes
 
   function c_loc_3d(a) result(p)
     real(wp), dimension(:,:,:), intent(in), target, contiguous :: a

@@ -163,3 +163,28 @@ def test_fortran_fluxes_byband(pkg, gpu, oracle_mod, tmp_path, mode, dev):
                                                                helpers.oracle_gas_items(cols, names), cols["tlev"])
         ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], m.ng, 0), sfc)
     assert np.max(np.abs(fu - ofu)) < FLUX_ATOL and np.max(np.abs(fd - ofd)) < FLUX_ATOL
+
+
+@pytest.mark.gpu
+def test_fortran_fused_lw_fluxes(pkg, gpu, oracle_mod, tmp_path):
+    """ecckd%lw_fluxes (type-bound extension over ecckd_lw_fluxes: the fused longwave path) gives the fluxes of
+    ecckd%gas_optics + rte_lw to the fp64 bar, block by block, 3 quadrature angles."""
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    m = oracle_mod.CkdModel(LW_FSCK)
+    ncol = 250
+    cols = synthetic.columns(77, ncol, float(np.exp(m.log_pressure[0])))
+    names = synthetic.GAS_ORDER
+    write_input(tmp_path / "in.bin", cols, names, False)
+    out = {}
+    for fused in ("0", "1"):
+        r = subprocess.run([drv, "lw", LW_FSCK, str(tmp_path / "in.bin"), str(tmp_path / ("o%s.bin" % fused)), "100", "3", "0", "1", "0", fused],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out[fused] = read_output(tmp_path / ("o%s.bin" % fused), ncol, 60)
+    assert np.max(np.abs(out["0"][0] - out["1"][0])) < FLUX_ATOL and np.max(np.abs(out["0"][1] - out["1"][1])) < FLUX_ATOL
+    tau, lay, inc, dec, sfc, _ = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"],
+                                                           helpers.oracle_gas_items(cols, names), cols["tlev"])
+    ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], 32, 0), sfc, nmus=3)
+    assert np.max(np.abs(out["1"][0] - ofu)) < FLUX_ATOL and np.max(np.abs(out["1"][1] - ofd)) < FLUX_ATOL

@@ -590,10 +590,21 @@ def test_fused_lw_path_vs_oracle(pkg, gpu, oracle_mod, lw, split_solver, seg):
     ok = np.isfinite(fu)
     assert np.max(np.abs(fl.flux_up.cpu().numpy()[::-1] - fu)[ok]) < FLUX_ATOL
     assert np.max(np.abs(fl.flux_dn.cpu().numpy()[::-1] - fd)[ok]) < FLUX_ATOL
-    # other layer counts are refused with a message, not mis-computed
-    op5 = pkg.OpticalProps1scl(); op5.tau = t(np.zeros((ng, 5, 8))); op5.band2gpt = k.get_band2gpt()
-    fl5 = pkg.FluxesBroadband(torch.zeros((6, 8), dtype=torch.float64, device=gpu), torch.zeros((6, 8), dtype=torch.float64, device=gpu))
-    assert "60 layers" in k.rte_lw_fused(op5, True, t(np.full((5, 8), 250.)), t(np.full((6, 8), 250.)), t(np.full(8, 250.)), t(np.ones((8, 1))), fl5)
+    # other layer counts take the general route inside the same entry points (Planck kernel into library scratch, then the
+    # register-resident solver; 137 layers also exercises its ring): same results
+    for nl in (37, 137):
+        c2 = synthetic.columns(5, 130, k.get_press_min(), nlay=nl)
+        gc2 = helpers.product_gas_concs(pkg, c2, t)
+        fl2 = pkg.FluxesBroadband(torch.zeros((nl + 1, 130), dtype=torch.float64, device=gpu), torch.zeros((nl + 1, 130), dtype=torch.float64, device=gpu))
+        e2 = c2["sfc_emis"][:, None]
+        assert k.lw_fluxes(t(c2["plev"]), t(c2["tlay"]), t(c2["tsfc"]), t(c2["tlev"]), gc2, True, t(e2), fl2, n_gauss_angles=2) == ""
+        o = oracle_mod.gas_optics_int(m, c2["plev"], c2["tlay"], c2["tsfc"], helpers.oracle_gas_items(c2), c2["tlev"])
+        fu, fd = oracle_mod.rte_lw(o[0], o[1], o[2], o[3], np.repeat(e2.T, ng, 0), o[4], nmus=2)
+        assert np.max(np.abs(fl2.flux_up.cpu().numpy() - fu)) < FLUX_ATOL and np.max(np.abs(fl2.flux_dn.cpu().numpy() - fd)) < FLUX_ATOL
+        hfl2 = pkg.FluxesBroadband(np.zeros((nl + 1, 130)), np.zeros((nl + 1, 130)))
+        assert k.lw_fluxes(c2["plev"], c2["tlay"], c2["tsfc"], c2["tlev"], helpers.product_gas_concs(pkg, c2), True, np.ascontiguousarray(e2), hfl2,
+                           n_gauss_angles=2) == ""
+        assert np.array_equal(hfl2.flux_up, fl2.flux_up.cpu().numpy())
 
 
 # ------------------------------------------------------------------------------------------------
