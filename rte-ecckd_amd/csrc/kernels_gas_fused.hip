@@ -98,9 +98,11 @@ __host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, i
 // host: d finite, non-zero, significand not all ones; otherwise exact is 0 and `/` is used.)
 template <typename real> struct UDivT { real d, r; int exact; };
 template <typename real> __device__ __forceinline__ UDivT<real> make_udiv_t(const UDiv &u) {
+  // d and r come from the host already rounded to the working precision (make_udiv): they stay in SGPRs.  (Computing
+  // 1/d here cost a division sequence per thread and two VGPRs per divisor for the whole kernel.)
   UDivT<real> o;
   o.d = (real)u.d;
-  o.r = real(1) / o.d;   // correctly rounded reciprocal in the working precision
+  o.r = (real)u.r;
   o.exact = u.exact;
   return o;
 }
@@ -846,7 +848,7 @@ UDiv make_udiv(double d, int f32) {
   UDiv u;
   if (f32) d = (double)(float)d;   // the kernel works with the rounded divisor
   u.d = d;
-  u.r = 1. / d;
+  u.r = f32 ? (double)(1.f / (float)d) : 1. / d;   // correctly rounded reciprocal in the working precision
   unsigned long long bits;
   static_assert(sizeof(bits) == sizeof(d), "");
   __builtin_memcpy(&bits, &d, 8);
