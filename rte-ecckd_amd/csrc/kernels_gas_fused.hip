@@ -62,6 +62,40 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// Order of the items of a chunk.  Item INDICES are: [0, NLI) look_up_table gas (g-pair p, vmr plane h: index 2p + h),
+// [NLI, NLI+NBI) bilinear slots, then NPI Planck items (g-pair p: index p; first layer only: NP2 + p).  Every g-pair ends
+// in stores: tau once its last slot is in, three or four source planes per Planck item.  ECCKD_FUSED_INTERLEAVE:
+//   0  slot-major: all look_up_table items, all bilinear items (slot outer, g-pair inner), all Planck items -- the stores
+//      of a chunk come as one burst of 16-20 KiB per wave at its end;
+//   1  (default) the same with the Planck items spread between the bilinear items: -0.4 % in fp64, -5.5 % in fp32;
+//   2  g-pair-major: per g-pair its look_up_table items, its slots, its Planck item(s) -- four stores every tenth item;
+//      the slot addresses stay live across the pairs and the 8-g-point double instantiation spills 29 VGPRs: measured
+//      equal to 1 in fp64 and 2 % slower in fp32 (round 2, same box).
+// The arithmetic per g-point is the same in every order (look_up_table gas first, then the slots in order).
+// seq_item(pos) = index of the item at position pos of the chunk's sequence; bil_slot / bil_pair decode a bilinear index.
+#ifndef ECCKD_FUSED_INTERLEAVE
+#define ECCKD_FUSED_INTERLEAVE 1
+#endif
+constexpr int seq_item(int pos, int NLI, int NBI, int NPI, int NP2) {
+  if (ECCKD_FUSED_INTERLEAVE == 2) {
+    const int NB = NBI / NP2, npl = NPI / NP2, per_pair = 2 + NB + npl;
+    const int p = pos / per_pair, r = pos % per_pair;
+    if (r < 2) return 2 * p + r;
+    if (r < 2 + NB) return NLI + p * NB + (r - 2);
+    return NLI + NBI + (r - 2 - NB) * NP2 + p;
+  }
+  if (ECCKD_FUSED_INTERLEAVE == 0 || NPI == 0 || pos < NLI) return pos;
+  int r = pos - NLI, b = 0, k = 0;   // r-th item after the look_up_table items
+  for (int q = 0;; ++q) {
+    // Planck item k follows bilinear item ((2k+1)*NBI)/(2*NPI) - 1
+    const bool planck_next = k < NPI && b >= ((2 * k + 1) * NBI) / (2 * NPI);
+    if (q == r) return planck_next ? NLI + NBI + k : NLI + b;
+    if (planck_next) ++k; else ++b;
+  }
+}
+constexpr int bil_slot(int b, int NB, int NP2) { return ECCKD_FUSED_INTERLEAVE == 2 ? b % NB : b / NP2; }
+constexpr int bil_pair(int b, int NB, int NP2) { return ECCKD_FUSED_INTERLEAVE == 2 ? b / NB : b % NP2; }
+
 template <typename real> __device__ __forceinline__ real selmin(real a, real b) { return a < b ? a : b; }
 template <typename real> __device__ __forceinline__ real selmax(real a, real b) { return a > b ? a : b; }
 
@@ -562,22 +596,23 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
           const int pb = L.pl + gb;
           double2_t buf[2][4];
           real lutp[2] = {real(0), real(0)};
-          static_for<0, NIT + 1>([&](auto it_c) __attribute__((always_inline)) {
-            constexpr int it = decltype(it_c)::value;
+          static_for<0, NIT + 1>([&](auto pos_c) __attribute__((always_inline)) {
+            constexpr int pos = decltype(pos_c)::value;                       // position in the sequence
+            constexpr int it = pos < NIT ? seq_item(pos, NLI, NBI, NPI, NP2) : NIT;    // item read at this position
             // ---------------- issue the reads of item `it` ----------------
             if constexpr (it < NLI) {                       // look_up_table gas: g-points 2*pr, 2*pr+1, vmr plane h
               const int g = 2 * (it / 2), h = it & 1;
-              double2_t *b = buf[it & 1];
+              double2_t *b = buf[pos & 1];
               const int o = ol + h * dVl + g;
               b[0] = ld2(o); b[1] = ld2(o + dPl); b[2] = ld2(o + dTl); b[3] = ld2(o + dTl + dPl);
             } else if constexpr (it < NLI + NBI) {          // one bilinear slot, one g-pair
-              const int s = (it - NLI) / NP2, g = 2 * ((it - NLI) % NP2);
-              double2_t *b = buf[it & 1];
+              const int s = bil_slot(it - NLI, NB, NP2), g = 2 * bil_pair(it - NLI, NB, NP2);
+              double2_t *b = buf[pos & 1];
               const int o = ob + s * ngp + g;
               b[0] = ld2(o); b[1] = ld2(o + dPb); b[2] = ld2(o + dTb); b[3] = ld2(o + dTb + dPb);
             } else if constexpr (it < NIT) {                // Planck sources of one g-pair
               constexpr int k = it - NLI - NBI;
-              double2_t *b = buf[it & 1];
+              double2_t *b = buf[pos & 1];
               if constexpr (k < NP2) {                      // layer and level j+1
                 const int g = 2 * k;
                 b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
@@ -588,9 +623,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
               }
             }
             // ---------------- arithmetic of item `it - 1` ----------------
-            if constexpr (it >= 1) {
-              constexpr int pi_ = it - 1;
-              const double2_t *b = buf[pi_ & 1];
+            if constexpr (pos >= 1) {
+              constexpr int pi_ = seq_item(pos - 1, NLI, NBI, NPI, NP2);       // the item read at the previous position
+              const double2_t *b = buf[(pos - 1) & 1];
               if constexpr (pi_ < NLI) {
                 const int g0 = 2 * (pi_ / 2);
                 if ((pi_ & 1) == 0) {
@@ -613,7 +648,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   }
                 }
               } else if constexpr (pi_ < NLI + NBI) {
-                const int s = (pi_ - NLI) / NP2, g0 = 2 * ((pi_ - NLI) % NP2);
+                constexpr int s = bil_slot(pi_ - NLI, NB, NP2), g0 = 2 * bil_pair(pi_ - NLI, NB, NP2);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                   real v = a00 * b[0][q];
@@ -622,9 +657,12 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
                   asm volatile("" : "+v"(acc[g0 + q]));
                 }
-                if (pi_ == NLI + NBI - 1) {   // tau of this chunk is complete
+                // tau is complete: of the whole chunk after its last bilinear item, or (g-pair-major order) of this
+                // g-pair after its last slot
+                constexpr bool pair_major = ECCKD_FUSED_INTERLEAVE == 2;
+                if (pair_major ? s == NB - 1 : pi_ == NLI + NBI - 1) {
 #pragma unroll
-                  for (int g = 0; g < GC; g += 2) {
+                  for (int g = pair_major ? g0 : 0; g < (pair_major ? g0 + 2 : GC); g += 2) {
                     if (FULL || gb + g + 1 < ng) {
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
