@@ -191,6 +191,9 @@ def fortran_device_resident(pkg, lw_file, n, press_min, ng):
     return res
 
 
+WELL_MIXED = dict(co2=420e-6, ch4=1.9e-6, n2o=3.3e-7, cfc11=2.3e-10, cfc12=5.2e-10)
+
+
 class LwCase:
     """Device-resident inputs, intermediates and outputs of one LW gas_optics + rte_lw workload (columns
     c0 .. c0+ncol-1 of the counter-based synthetic generator) and the step that runs it."""
@@ -216,13 +219,18 @@ class LwCase:
             for key, dst in self.percol.items():
                 dst[s0:s0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
         self.gc = pkg.GasConcs(synthetic.GAS_ORDER)
+        # RFMIP's description of the same gases (mo_rfmip_io.F90: <gas>_GM): one number per well-mixed gas for the call
+        self.gc_scalars = pkg.GasConcs(synthetic.GAS_ORDER)
         for name in synthetic.GAS_ORDER:
             if name in ("h2o", "o3"):
                 self.gc.set_vmr(name, h2o if name == "h2o" else o3)
+                self.gc_scalars.set_vmr(name, h2o if name == "h2o" else o3)
             elif name in self.percol:
                 self.gc.set_vmr_column(name, self.percol[name])
+                self.gc_scalars.set_vmr(name, WELL_MIXED[name])
             else:
                 self.gc.set_vmr(name, 0.209 if name == "o2" else 0.0)
+                self.gc_scalars.set_vmr(name, 0.209 if name == "o2" else 0.0)
         self.emis = self.percol["sfc_emis"].reshape(ncol, 1).expand(ncol, k.get_nband()).contiguous()
         self.op = pkg.OpticalProps1scl()
         self.op.alloc_1scl(ncol, nlay, k, like=self.plev)
@@ -468,6 +476,7 @@ def main():
         # fused longwave path -- gas optics writes tau only, the solver recomputes the Planck sources (16 instead of
         # 64 B/cell between the kernels; bound by fp64 issue, not HBM: reported apart from the API-boundary roofline).
         out["lw_solver_variants"] = None
+        out["well_mixed_scalars"] = None
         out["fused_lw"] = None
         if side and args.dtype == "f64" and args.arithmetic == "fast":
             saved = pkg.get_solver_option("lw_solver")
@@ -485,6 +494,32 @@ def main():
                 var[label] = {"rte_lw_ms": (time.perf_counter() - t0) / args.steps * 1e3}
             pkg.set_solver_option("lw_solver", saved); pkg.set_solver_option("lw_split_seg", 10)
             out["lw_solver_variants"] = var
+            # (c) the same columns with the well-mixed gases described as RFMIP describes them -- one number per gas for
+            # the call instead of one per column: the gas-optics kernel folds them and the composite into one table
+            # ("gas_merge_scalars"); h2o and o3 stay profiles.  Not the headline (BASELINE's inputs vary them per column).
+            def sstep():
+                e = k.gas_optics(None, case.plev, case.tlay, case.percol["tsfc"], case.gc_scalars, op, src, tlev=case.tlev)
+                e = e or pkg.rte_lw(op, True, src, emis, fl, n_gauss_angles=1)
+                if e:
+                    raise SystemExit(e)
+            for _ in range(max(args.warmup, 1)):
+                sstep()
+            torch.cuda.synchronize()
+            L.ecckd_prof_enable(1)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sstep()
+            torch.cuda.synchronize()
+            ms_s = (time.perf_counter() - t0) / args.steps * 1e3
+            L.ecckd_prof_enable(0)
+            ks = prof_report(L)
+            pl = k.plan(ncol, nlay, synthetic.GAS_ORDER, scalar_gases=list(WELL_MIXED) + ["o2", "no2"])
+            out["well_mixed_scalars"] = {
+                "value": cells_per_gpu / (ms_s * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": ms_s,
+                "frac_of_hbm_roofline": total_b / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernels_avg_ms": {n: v[0] for n, v in ks.items()}, "gases_merged": pl["merged"], "slots": pl["slots"],
+                "note": "co2, ch4, n2o, cfc11, cfc12 as one number each (RFMIP's *_GM), o2 0.209; same kernels, same API"}
+            case.step()          # the headline's arrays back in op / src for what follows
             if nlay == 60:
                 ref_up, ref_dn = fl.flux_up.clone(), fl.flux_dn.clone()
                 tsfc_d = case.percol["tsfc"]
@@ -514,6 +549,25 @@ def main():
                     "hbm_bytes_per_cell_between_kernels": 16, "bound": "fp64 VALU issue (not HBM): not quoted against the HBM roofline",
                     "max_abs_flux_diff_vs_api_path_Wm2": dmax,
                     "note": "ecckd_lw_fluxes: ecckd_gas_optics_lw_tau + ecckd_rte_lw_fused; same inputs, same fluxes"}
+                # the fused path on the RFMIP-style gas description (side measurement (c) above)
+                def fsstep():
+                    e = k.lw_fluxes(case.plev, case.tlay, tsfc_d, case.tlev, case.gc_scalars, True, emis, fl, n_gauss_angles=1)
+                    if e:
+                        raise SystemExit(e)
+                for _ in range(max(args.warmup, 1)):
+                    fsstep()
+                torch.cuda.synchronize()
+                L.ecckd_prof_enable(1)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fsstep()
+                torch.cuda.synchronize()
+                ms_fs = (time.perf_counter() - t0) / args.steps * 1e3
+                L.ecckd_prof_enable(0)
+                kfs = prof_report(L)
+                out["fused_lw"]["well_mixed_scalars"] = {
+                    "value": cells_per_gpu / (ms_fs * 1e-3) / 1e6, "ms_per_step": ms_fs,
+                    "speedup_vs_headline": ms_per_step / ms_fs, "kernels_avg_ms": {n: v[0] for n, v in kfs.items()}}
                 src = None
                 pkg.release_scratch(local_rank)
         del case, fl, op, src, emis

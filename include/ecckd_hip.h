@@ -305,6 +305,16 @@ int ecckd_device_free(int device, void *ptr);
 int ecckd_device_memcpy(int device, void *dst, const void *src, size_t bytes, int to_device);
 
 /* ---------------------------------------------------------------------------------------
+ * calculate_planck_function x 3 alone (src/gas_optics_ecckd.f90:245-289 as gas_optics_int applies it, :407-424):
+ * lay_source(ncol,nlay,ngpt) from tlay, lev_source_inc / lev_source_dec from tlev(ncol,nlay+1) (tlev may be NULL: the
+ * level sources are then left alone), sfc_source(ncol,ngpt) from tsfc.  Device arrays (ECCKD_DEVICE), fp64,
+ * asynchronous on `stream`.  The same kernel ecckd_gas_optics_lw runs beside its optical-depth kernel.
+ * --------------------------------------------------------------------------------------- */
+int ecckd_planck_sources(const ecckd_model_t *model, int ncol, int nlay, const double *tlay, const double *tlev,
+                         const double *tsfc, double *lay_source, double *lev_source_inc, double *lev_source_dec,
+                         double *sfc_source, int memspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Launch plan of a gas_optics call (no counterpart in the reference; works on host-only models,
  * device -1, and launches nothing): how the library would run gas_optics for this model, gas list
  * (names only; LW if the model has a Planck table, else SW), size, precision and the current
@@ -318,6 +328,13 @@ int ecckd_device_memcpy(int device, void *dst, const void *src, size_t bytes, in
  * --------------------------------------------------------------------------------------- */
 int ecckd_gas_optics_plan(const ecckd_model_t *model, int ncol, int nlay, int single_precision,
                           int ngas, const char *gas_names, int *plan);
+/* The same with the shape of gas_desc: vmr_is_scalar[j] != 0 says gas j would be passed as one number (a null
+ * pointer: every gas is an array).  Writes min(nplan, ECCKD_PLAN_LEN) entries; beyond the eight above:
+ *   plan[8] bilinear slots of the kernel instantiation (2, 5, 7 or 10)
+ *   plan[9] gases folded into the merged slot ("gas_merge_scalars" below; 0: none) */
+#define ECCKD_PLAN_LEN 10
+int ecckd_gas_optics_plan_ex(const ecckd_model_t *model, int ncol, int nlay, int single_precision,
+                             int ngas, const char *gas_names, const int *vmr_is_scalar, int nplan, int *plan);
 
 /* ---------------------------------------------------------------------------------------
  * Arithmetic mode of gas_optics (process-wide, atomic; read once per call).
@@ -351,6 +368,13 @@ int ecckd_get_arithmetic(void);
  *   "lw_solver"              fp64, 60 layers: 0 register-resident solver (one wave per SIMD), 1 layer-split solver
  *                            (waves of a block share a tile and take 10-15 layers each; three waves per SIMD)
  *   "lw_split_seg"           layers per wave of the layer-split solver: 10 (default), 12 or 15
+ *   "gas_merge_scalars"      fast arithmetic mode: 1 (default) the gases of gas_desc given as ONE number for the call
+ *                            (vmr pointer NULL + vmr_scalar; get_vmr broadcasts them, src/gas_optics_ecckd.f90:351) and
+ *                            the none_ composite share one table sum_k m_k*coefficient_k, m_k = vmr | vmr - reference | 1,
+ *                            built on the fly: tau = ... + simple_weight * bilinear(merged table) instead of one
+ *                            interpolation per gas (same real-number formula; the per-gas clamp :234-238 is kept
+ *                            because only gases with m_k >= 0 and tables without negative entries are merged);
+ *                            0: every gas interpolated on its own
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_solver_option(const char *name, double value);
 int ecckd_get_solver_option(const char *name, double *value);

@@ -158,7 +158,10 @@ def lib():
     L.ecckd_model_destroy.restype = None
     L.ecckd_model_add_gas.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_double, C.c_void_p]
+    L.ecckd_planck_sources.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
     L.ecckd_gas_optics_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+    L.ecckd_gas_optics_plan_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int,
+                                           C.c_void_p]
     L.ecckd_set_solver_option.argtypes = [C.c_char_p, C.c_double]
     L.ecckd_get_solver_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
     for f in ("ecckd_rte_lw_scratch_bytes", "ecckd_rte_sw_scratch_bytes"):
@@ -189,7 +192,7 @@ def get_arithmetic():
 
 
 SOLVER_OPTIONS = ("lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor", "sw_dir_clamp", "lw_solver",
-                  "lw_split_seg")
+                  "lw_split_seg", "gas_merge_scalars")
 
 
 def set_solver_option(name, value):
@@ -555,16 +558,20 @@ class GasOpticsEcckd:
     def source_is_external(self):
         return bool(lib().ecckd_model_source_is_external(self._need()))
 
-    def plan(self, ncol, nlay, gas_names, single_precision=False):
-        """``ecckd_gas_optics_plan``: how gas_optics would run for this model, gas list and size (works
-        without a GPU on a ``device=-1`` model).  Returns a dict, or raises RuntimeError with the
+    def plan(self, ncol, nlay, gas_names, single_precision=False, scalar_gases=()):
+        """``ecckd_gas_optics_plan_ex``: how gas_optics would run for this model, gas list and size (works
+        without a GPU on a ``device=-1`` model).  ``scalar_gases`` names the gases that would be passed as
+        one number (they can share the merged slot).  Returns a dict, or raises RuntimeError with the
         library's message."""
         names = b"".join(n.strip().lower().encode().ljust(NAME_LEN, b" ") for n in gas_names)
-        out = (C.c_int * 8)()
-        if lib().ecckd_gas_optics_plan(self._need(), int(ncol), int(nlay), int(bool(single_precision)),
-                                       len(gas_names), names, out):
+        sc = {n.strip().lower() for n in scalar_gases}
+        flags = (C.c_int * max(1, len(gas_names)))(*[int(n.strip().lower() in sc) for n in gas_names])
+        out = (C.c_int * 10)()
+        if lib().ecckd_gas_optics_plan_ex(self._need(), int(ncol), int(nlay), int(bool(single_precision)),
+                                          len(gas_names), names, flags, 10, out):
             raise RuntimeError(last_error())
-        keys = ("passes", "fused", "planck_fused", "slab_rows", "planck_rows", "col_chunks", "lds_bytes", "g_chunk")
+        keys = ("passes", "fused", "planck_fused", "slab_rows", "planck_rows", "col_chunks", "lds_bytes", "g_chunk",
+                "slots", "merged")
         return dict(zip(keys, list(out)))
 
     def get_press_min(self):
@@ -644,6 +651,20 @@ class GasOpticsEcckd:
                 P(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
                 P(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
         sources.levels_shared = rc == 0 and tlev is not None
+        return last_error() if rc else ""
+
+    def planck_sources(self, tlay, tsfc, sources, tlev=None):
+        """``ecckd_planck_sources``: the four Planck source arrays alone (device tensors, fp64)."""
+        nlay, ncol = tlay.shape
+        ng = self.get_ngpt()
+        space = _space_of([tlay, tsfc, sources.lay_source])
+        rc = lib().ecckd_planck_sources(
+            self._need(), ncol, nlay, _ptr(tlay, (nlay, ncol), "tlay"),
+            None if tlev is None else _ptr(tlev, (nlay + 1, ncol), "tlev"), _ptr(tsfc, (ncol,), "tsfc"),
+            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            None if tlev is None else _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            None if tlev is None else _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), space, _stream(space))
         return last_error() if rc else ""
 
     def gas_optics_tau(self, plev, tlay, gas_desc, optical_props):

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -127,6 +128,7 @@ thread_local const double *g_inc_flux = nullptr;   // set by ecckd_rte_lw_inc_fl
 thread_local int g_band_override = -1;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
 struct PlanRecord {
+  const int *is_scalar = nullptr;   // per gas of the list: its mole fraction would be passed as one number
   int npass = 0, first_fused = 0, planck_fused = 0;
   ecckd::FusedPlan first;
 };
@@ -155,6 +157,8 @@ struct SolverOptions {
   // implementation choices (same results to ~1e-16 relative): which fp64 / 60-layer longwave solver runs
   std::atomic<int> lw_solver{ECCKD_LW_DEFAULT_SOLVER};   // 0 register-resident (kernels_rte_lw.hip), 1 layer-split
   std::atomic<int> lw_split_seg{10};
+  // ... and whether the call-constant gases of a pass share one slab slot (merge_scalar_gases(); ~1e-16 relative on tau)
+  std::atomic<int> gas_merge_scalars{1};
 };
 SolverOptions g_opt;
 
@@ -238,6 +242,11 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     e.cs = gd.cs ? gd.cs[j] : 0;
     e.ls = gd.ls ? gd.ls[j] : 0;
     e.scalar = gd.scalar ? gd.scalar[j] : 0.;
+    if (g_plan) {   // no data in a plan call: an array gas gets a (never dereferenced) non-null marker, a scalar one 1.0
+      const bool sc = g_plan->is_scalar && g_plan->is_scalar[j];
+      e.vmr = sc ? nullptr : reinterpret_cast<const double *>(sizeof(double));
+      e.scalar = 1.;
+    }
     e.ref = t.ref;
     e.code = t.code;
     e.nv = t.nv;
@@ -271,6 +280,8 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     a.gw = 1. / ((double)9.80665f * (double)0.001f * (double)28.970f);
     if (g_f32) a.gw = (double)(1.f / (9.80665f * 0.001f * 28.970f));   // the same expression with wp = float
     a.lut = -1;
+    a.merge_slot = -1;
+    a.nmerge = 0;
     a.nbil = 0;
     a.nseq = 0;
     while (pos < seq.size()) {
@@ -296,6 +307,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     }
     if (fast) {
       fa.mode = (sw && last) ? 2 : 0;
+      if (g_opt.gas_merge_scalars.load()) merge_scalar_gases(a, g_f32);
       const int nv_lut = a.lut >= 0 ? a.seq[a.lut].nv : 0;
       // Planck sources ride along with the first pass when the table, or a window of it, fits next
       // to >= 3 slab rows
@@ -476,8 +488,9 @@ int ecckd_set_solver_option(const char *name, double value) {
   } else if (n == "lw_split_seg") {
     if (value != 10. && value != 12. && value != 15.) return fail("ecckd_set_solver_option: lw_split_seg must be 10, 12 or 15");
     g_opt.lw_split_seg.store((int)value);
-  } else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
-                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg)");
+  } else if (n == "gas_merge_scalars") g_opt.gas_merge_scalars.store(value != 0. ? 1 : 0);
+  else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars)");
   return 0;
 }
 
@@ -491,6 +504,7 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "sw_dir_clamp") *value = g_opt.sw_dir_clamp.load();
   else if (n == "lw_solver") *value = g_opt.lw_solver.load();
   else if (n == "lw_split_seg") *value = g_opt.lw_split_seg.load();
+  else if (n == "gas_merge_scalars") *value = g_opt.gas_merge_scalars.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -787,18 +801,55 @@ static int gas_optics_lw_dev(const ecckd_model *m, int ncol, int nlay, const dou
   p.sfc_source = sfc_source;
   {
     ProfScope prof("planck", stream);
-    HIPCHK(ecckd::launch_planck(p, stream));                        // :407-424
+    // :407-424; the fast arithmetic mode takes the kernel with paired 16-byte stores (same bits)
+    if (g_arith.load() == 0) HIPCHK(ecckd::launch_planck_pair(p, 0, stream));
+    else HIPCHK(ecckd::launch_planck(p, stream));
   }
+  return 0;
+}
+
+int ecckd_planck_sources(const ecckd_model_t *m, int ncol, int nlay, const double *tlay, const double *tlev,
+                         const double *tsfc, double *lay_source, double *lev_source_inc, double *lev_source_dec,
+                         double *sfc_source, int memspace, void *stream) {
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
+  if (!m->has_planck) return fail("ecckd_planck_sources: model has no Planck table (shortwave model?)");
+  if (memspace != ECCKD_DEVICE) return fail("ecckd_planck_sources: device arrays only (ECCKD_DEVICE)");
+  if (!tlay || !tsfc || !lay_source || !sfc_source) return fail("ecckd_planck_sources: null argument");
+  if (tlev && (!lev_source_inc || !lev_source_dec)) return fail("ecckd_planck_sources: null level sources");
+  HIPCHK(hipSetDevice(m->device));
+  if (ncol == 0) return 0;
+  ecckd::PlanckArgs p{};
+  p.ncol = ncol; p.nlay = nlay; p.ng = m->ng; p.ntp = m->ntp;
+  p.planck = m->dbuf + m->off_planck;
+  p.t0 = m->temperature_planck[0];                                  // :272
+  p.dt = m->temperature_planck[1] - m->temperature_planck[0];      // :271
+  p.tlay = tlay; p.tlev = tlev; p.tsfc = tsfc;
+  p.lay_source = lay_source; p.lev_source_inc = lev_source_inc; p.lev_source_dec = lev_source_dec;
+  p.sfc_source = sfc_source;
+  ProfScope prof("planck", static_cast<hipStream_t>(stream));
+  if (g_arith.load() == 0) HIPCHK(ecckd::launch_planck_pair(p, 0, static_cast<hipStream_t>(stream)));
+  else HIPCHK(ecckd::launch_planck(p, static_cast<hipStream_t>(stream)));
   return 0;
 }
 
 int ecckd_gas_optics_plan(const ecckd_model_t *m, int ncol, int nlay, int single_precision, int ngas,
                           const char *gas_names, int *plan) {
+  int p[ECCKD_PLAN_LEN];
+  if (ecckd_gas_optics_plan_ex(m, ncol, nlay, single_precision, ngas, gas_names, nullptr, ECCKD_PLAN_LEN, p)) return 1;
+  if (!plan) return fail("ecckd_gas_optics_plan: null argument");
+  for (int i = 0; i < 8; ++i) plan[i] = p[i];
+  return 0;
+}
+
+int ecckd_gas_optics_plan_ex(const ecckd_model_t *m, int ncol, int nlay, int single_precision, int ngas,
+                             const char *gas_names, const int *vmr_is_scalar, int nplan, int *plan_out) {
   if (!m) return fail("ecckd: null model");
   if (!m->finalized) return fail("ecckd: model is not finalized");
   if (check_gas_optics_dims(ncol, nlay)) return 1;
-  if (!plan || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_plan: null argument");
+  if (!plan_out || nplan < 1 || (ngas > 0 && !gas_names)) return fail("ecckd_gas_optics_plan: null argument");
+  int plan[ECCKD_PLAN_LEN] = {0};
   PlanRecord rec;
+  rec.is_scalar = vmr_is_scalar;
   const GasDesc gd{ngas, gas_names, nullptr, nullptr, nullptr, nullptr};
   const PlanckSide pl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const bool lw = m->has_planck;
@@ -818,6 +869,9 @@ int ecckd_gas_optics_plan(const ecckd_model_t *m, int ncol, int nlay, int single
   plan[5] = rec.first.col_chunks;
   plan[6] = (int)rec.first.lds_bytes;
   plan[7] = rec.first.GC;
+  plan[8] = rec.first.NB;
+  plan[9] = rec.first.merged;
+  for (int i = 0; i < nplan && i < ECCKD_PLAN_LEN; ++i) plan_out[i] = plan[i];
   return 0;
 }
 

@@ -38,6 +38,13 @@ struct TauArgs {
   int nbil;                    // bilinear gases in this pass (slab row holds nbil*ng values)
   int bil_seq[kMaxSeq];        // slab slot -> index into seq
   int lut;                     // index into seq of the look_up_table gas, or -1
+  // Merged slot (fused kernel, fast arithmetic; merge_scalar_gases()): the gases of this pass whose mole fraction is one
+  // number for the whole call -- scalar entries of gas_desc and the none_ composite -- share ONE slab slot holding
+  // sum_k merge_mult[k] * coefficient_k, built while the slab is staged; its weight is simple_weight alone.
+  int merge_slot;              // slab slot of the merged table, or -1
+  int nmerge;                  // gases in it (0 or >= 2)
+  int merge_seq[kMaxSeq];      // their indices into seq, in gas_desc order
+  double merge_mult[kMaxSeq];  // vmr, vmr - reference, or 1 (none_): >= 0, finite, rounded to the working precision
   int accumulate;              // start from the tau already in memory (later passes)
   double *tau;
   // shortwave epilogue (src/gas_optics_ecckd.f90:455-460); rayleigh == nullptr for LW
@@ -153,13 +160,21 @@ struct FusedPlan {
   int empty = 0;               // ncol == 0: nothing to launch
   size_t lds_bytes = 0;
   int anyclamp = 0, GC = 0, NB = 0;
+  int merged = 0;              // gases sharing the merged slot
   int slab_rows = 0, planck_rows = 0, col_chunks = 0;
 };
 hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan);
+// Folds the call-constant gases of a pass into one slot (TauArgs::merge_*); rewrites nbil / bil_seq.  Returns the number
+// of gases merged (0: nothing changed).  Only for the fused kernel (the reference-order kernels take each gas alone).
+int merge_scalar_gases(TauArgs &t, int f32);
 int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32);
 int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int anyclamp, int f32);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
+// the Planck sources as a stand-alone fast kernel (paired 16-byte stores)
+hipError_t launch_planck_pair(const PlanckArgs &a, int f32, hipStream_t s);
+size_t planck_pair_lds_bytes(int ng, int ntp, int f32);
+UDiv make_udiv(double d, int f32);
 hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);
 // out(i) = sum_b planes(i, b): broadband from per-band fluxes
 hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double *out, int f32, hipStream_t s);

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "wave_pair.hpp"
 
 namespace ecckd {
 namespace {
@@ -103,11 +104,6 @@ struct FLayout {
   int tb, red, bil, SB, lut, SL, pl, SP, total;
 };
 
-// Row strides are == 2 (mod 4) doubles: every row starts 16-byte aligned (ds_read_b128 of two
-// consecutive g-points) and consecutive rows are shifted by 4 banks, so the 16 lanes of a b128
-// lane group that sit in different rows do not collide.
-__host__ __device__ inline int row_stride(int n) { return n + ((6 - (n & 3)) & 3); }
-
 // NB  = bilinear slots the kernel reads per row (>= nbil; the slab is followed by a pad so that the
 //       zero-weight slots read finite data).
 // ngp = g-points per row in LDS: ng rounded up to the chunk size GC (the tail stays zero).
@@ -126,27 +122,6 @@ __host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, i
   return L;
 }
 
-// x / d for a wave-uniform divisor d with r = 1/d precomputed (correctly rounded): Markstein's
-// correction step returns the correctly rounded quotient, i.e. exactly what `x / d` returns, in
-// 3 instructions instead of the ~30 of the IEEE division sequence.  (Precondition checked on the
-// host: d finite, non-zero, significand not all ones; otherwise exact is 0 and `/` is used.)
-template <typename real> struct UDivT { real d, r; int exact; };
-template <typename real> __device__ __forceinline__ UDivT<real> make_udiv_t(const UDiv &u) {
-  // d and r come from the host already rounded to the working precision (make_udiv): they stay in SGPRs.  (Computing
-  // 1/d here cost a division sequence per thread and two VGPRs per divisor for the whole kernel.)
-  UDivT<real> o;
-  o.d = (real)u.d;
-  o.r = (real)u.r;
-  o.exact = u.exact;
-  return o;
-}
-template <typename real> __device__ __forceinline__ real udiv(real x, const UDivT<real> &u) {
-  if (!u.exact) return x / u.d;
-  const real q = x * u.r;
-  const real rem = fma(-q, u.d, x);
-  return fma(rem, u.r, q);
-}
-
 template <typename real> struct PPoint { int ip0; real pw0, pw1; };
 template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(real p0, real p1, real lp0, const UDivT<real> &dlp, int np) {
   const real log_pressure = log(real(0.5) * (p1 + p0));                      // :120
@@ -159,94 +134,7 @@ template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(
   return r;
 }
 
-// Planck interpolation point (:275-285): rows `row`, `row + 1` of the table (0-based) with weights
-// w0, w1.  Below the table the reference uses (T/t0)*B(:,1); that is row 0 with weights (T/t0, 0):
-// w0*b0 + 0*b1 == w0*b0 exactly, so no branch is needed.  `off` is filled in by the caller (LDS
-// offset of the row inside the staged window).
-template <typename real> struct PlPoint { int row, off; real w0, w1; };
-template <typename real> __device__ __forceinline__ PlPoint<real> planck_point(real Tk, real t0, const UDivT<real> &dt, int ntp) {
-  PlPoint<real> p;
-  real temperature_index = udiv(Tk - t0, dt);
-  if (temperature_index >= 0) {
-    temperature_index = real(1) + temperature_index;
-    const int it0 = temperature_index >= (real)(ntp - 1) ? ntp - 1 : (int)temperature_index;
-    p.w1 = temperature_index - it0;
-    p.w0 = real(1) - p.w1;
-    p.row = it0 - 1;
-  } else {
-    p.w0 = Tk / t0;
-    p.w1 = real(0);
-    p.row = 0;
-  }
-  p.off = 0;
-  return p;
-}
-
-template <typename real> __device__ __forceinline__ real div_pi(real x, real pi, real rpi) {
-  const real q = x * rpi;              // correctly rounded x/pi (Markstein), see kernels_planck.hip
-  const real r = fma(-q, pi, x);
-  return fma(r, rpi, q);
-}
-
 enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
-
-// Value of the neighbouring lane (lane ^ 1): two DPP moves, no LDS traffic.
-__device__ __forceinline__ double swap_adjacent(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float swap_adjacent(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
-}
-
-// Stores the values of two consecutive g-points (planes g, g+1 of a column-fastest array) as ONE
-// 16-byte store per lane instead of two 8-byte ones: the lanes of an (even, odd) column pair
-// exchange one value, then the even lane writes both columns of plane g and the odd lane both
-// columns of plane g+1.  Per CU the store path moves ~7 B/clk with dwordx2 and about twice that with
-// dwordx4 (the kernel was store-issue bound).  Called by all lanes of the wave.
-//   masked (wave-uniform) == false: every lane stores, no exec mask.
-//   masked == true: the wave holds lanes that are not handled in this pass (columns beyond ncol,
-//   or columns that belong to another slab position): the lanes with `active` store their own
-//   column of both planes with two 8-byte stores, the others store nothing.
-//   base: wave-uniform RUNNING pointer to (column 0, plane g) of the array, advanced by two planes
-//   (plane2 elements) after the store -- the g-pairs of an array are stored in ascending order, so
-//   one pointer per array walks the whole tile and nothing per (array, g-pair) is loop invariant;
-//   voff: per-lane BYTE offset sizeof(real) * ((c - odd) + (odd ? plane : 0)), 32 bits, shared by
-//   the four output arrays; coff: sizeof(real) * c.
-template <typename real>
-__device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned voff, unsigned coff, real v0, real v1,
-                                           bool odd, bool masked, bool active) {
-  typedef real double2_t __attribute__((ext_vector_type(2)));
-  // Pin the pointer in SGPRs right here: left alone, the optimiser precomputes one pointer per
-  // (array, g-pair) outside the loops (32 SGPRs, spilled to VGPR lanes and read back per store) or
-  // hoists the per-lane sum array + voff (32 VGPRs).
-  asm volatile("" : "+s"(base));
-  typedef __attribute__((address_space(1))) char gchar;          // global, not flat: the pin
-  typedef __attribute__((address_space(1))) double2_t gdouble2;  // hides the pointer's origin
-  typedef __attribute__((address_space(1))) real greal;
-  gchar *gbase = (gchar *)base;
-  if (!masked) {
-    const real recv = swap_adjacent(odd ? v0 : v1);
-    double2_t out;
-    out[0] = odd ? recv : v0;
-    out[1] = odd ? v1 : recv;
-#ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
-#ifndef ECCKD_PLAIN_STORES    // nontemporal: the outputs are written once and read by the next kernel
-    __builtin_nontemporal_store(out, reinterpret_cast<gdouble2 *>(gbase + voff));
-#else
-    *reinterpret_cast<gdouble2 *>(gbase + voff) = out;
-#endif
-#else
-    asm volatile("" :: "v"(out));
-#endif
-  } else if (active) {
-    *reinterpret_cast<greal *>(gbase + coff) = v0;
-    *reinterpret_cast<greal *>(gbase + (plane2 / 2) * (long)sizeof(real) + coff) = v1;
-  }
-  base += plane2;
-}
 
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
 __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
@@ -256,9 +144,12 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   typedef __attribute__((address_space(3))) const volatile real lds_cvd;
   typedef __attribute__((address_space(3))) const volatile double2_t lds_cvd2;
   lds_cvd *lv = (lds_cvd *)lds;
-  // two consecutive g-points in one ds_read_b128 (x must be even)
-  auto ld2 = [&](int x) -> double2_t { return *(lds_cvd2 *)(lv + x); };
+  // two consecutive g-points in one ds_read_b128
+  // (at a BYTE address plus a compile-time element offset, the immediate of the ds_read)
+  typedef __attribute__((address_space(3))) const volatile char lds_cvc;
+  auto ld2b = [&](int bytes, int elem) -> double2_t { return *(lds_cvd2 *)((lds_cvc *)lv + bytes + elem * (int)sizeof(real)); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wcol = (tid & ~63) + wave_column(lane);   // column of this thread inside a tile
   const int j = blockIdx.y;
   const TauArgs &t = a.tau;
   const int ncol = t.ncol, nlay = t.nlay, ng = t.ng, np = t.np, nt = t.nt, R = t.R;
@@ -375,6 +266,13 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       ipmin = pressure_point<real>(real(0), smin, lp0, ud_dlp, np).ip0;
       ipmax = pressure_point<real>(real(0), smax, lp0, ud_dlp, np).ip0;
     }
+    // Entry `o` of the merged table (TauArgs::merge_*).  The slab staging and the tables-from-global-memory path both
+    // go through this one expression: a column gets the same bits whichever path its wave takes.
+    auto merged_coef = [&](long o) -> real {
+      real v = (real)t.merge_mult[0] * P(t.seq[t.merge_seq[0]].coef)[o];
+      for (int k = 1; k < t.nmerge; ++k) v = fma((real)t.merge_mult[k], P(t.seq[t.merge_seq[k]].coef)[o], v);
+      return v;
+    };
     auto stage_slab = [&](int lo) {   // pressure rows [lo, lo + R) of every active table -> LDS
       slab_lo = lo;
       const int rows_b = R * nt;
@@ -382,9 +280,17 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       for (int q = wave; q < items_b; q += kWaves) {
         const int s = q % t.nbil, rb = q / t.nbil;
         const int ipl = rb % R, it = rb / R;
-        const real *src = P(t.seq[t.bil_seq[s]].coef) + (long)ng * ((slab_lo + ipl) + (long)np * it);
-        real *dst = lds + L.bil + rb * L.SB + s * ngp;
-        for (int g = lane; g < ng; g += 64) dst[g] = src[g];
+        const long row = (long)ng * ((slab_lo + ipl) + (long)np * it);
+        // a row holds [g-point chunk][slot][GC g-points]: inside a chunk every (slot, g-point) is a compile-time
+        // offset from the four corner addresses of the cell
+        real *dst = lds + L.bil + rb * L.SB + s * GC;
+        const int cs = t.nbil * GC;
+        if (s == t.merge_slot) {   // sum_k mult_k * coefficient_k: the call-constant gases as one table
+          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = merged_coef(row + g);
+        } else {
+          const real *src = P(t.seq[t.bil_seq[s]].coef) + row;
+          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = src[g];
+        }
       }
       if (t.lut >= 0) {
         const real *coef = P(t.seq[t.lut].coef);
@@ -423,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     // did not spill; with the slab-position logic in the kernel they do, and it measures -3 %.)
     real nx_p0, nx_p1, nx_T, nx_W[NB], nx_vlut, nx_Tl0 = real(0), nx_Tl1 = real(0);
     auto load_inputs = [&](long tile) {
-      const long c = tile * kBlock + tid;
+      const long c = tile * kBlock + wcol;
       const unsigned cc32 = (unsigned)(c < ncol ? c : (long)ncol - 1);
       const unsigned co = cc32 * (unsigned)sizeof(real);
       auto at = [&](const real *row) { return *reinterpret_cast<greal_t *>((gcchar_t *)row + co); };
@@ -439,9 +345,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
     };
 
     for (long tile = seg; tile < seg_end; ++tile) {
-      const long c = tile * kBlock + tid;
+      const long c = tile * kBlock + wcol;   // (see wave_column)
       const bool valid = c < ncol;
-      const bool odd = (tid & 1) != 0;
+      const bool upper = lane >= 32;        // this lane stores plane g+1 of its column pair
       const long cc = c < ncol ? c : (long)ncol - 1;
       // ---- setup: one round of global loads ----
       load_inputs(tile);
@@ -547,16 +453,27 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         static_assert(GC % 4 == 0, "chunks are made of g-point pairs");
         constexpr int NP2 = GC / 2;                                  // g-pairs per chunk
         constexpr int NLI = 2 * NP2, NBI = NB * NP2;
-        int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
-        int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
+        // LDS addresses (in elements): one register per corner row of the cell -- 4 for the bilinear slots, 8 for the
+        // look_up_table gas, 4 (6 in the first layer) for the Planck rows -- advanced once per chunk; everything
+        // inside a chunk is an immediate offset of the ds_read.  (Until round 2 the slot offset s*ngp was a run-time
+        // value: 80 v_add_u32 per chunk of eight g-points.)
+        const int ob = L.bil + (ipl + R * (it0 - 1)) * L.SB;
+        const int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
         const int dPb = L.SB, dTb = R * L.SB;
         const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
+        constexpr int ES = (int)sizeof(real);   // (the registers hold byte addresses)
+        int ab[4] = {ES * ob, ES * (ob + dPb), ES * (ob + dTb), ES * (ob + dTb + dPb)};
+        int al[8] = {ES * ol, ES * (ol + dPl), ES * (ol + dTl), ES * (ol + dTl + dPl),
+                     ES * (ol + dVl), ES * (ol + dVl + dPl), ES * (ol + dVl + dTl), ES * (ol + dVl + dTl + dPl)};
+        int ap[6] = {ES * (L.pl + qlay.off), ES * (L.pl + qlay.off + L.SP), ES * (L.pl + ql1.off), ES * (L.pl + ql1.off + L.SP),
+                     ES * (L.pl + ql0.off), ES * (L.pl + ql0.off + L.SP)};
+        const int cstride = ES * t.nbil * GC;   // a chunk of the bilinear row: [slot][GC]
         // Output addressing: a uniform plane pointer (SGPRs) plus ONE per-lane 32-bit byte
-        // offset shared by all four arrays -- even lanes write their column pair in plane g, odd
-        // lanes in plane g+1 (see store_pair).  launch_gas_fused() checks that it fits 32 bits.
+        // offset shared by all four arrays -- the lower half-wave writes column pairs of plane g, the upper
+        // half-wave those of plane g+1 (see store_pair).  launch_gas_fused() checks that it fits 32 bits.
         const unsigned plane = (unsigned)ncol * (unsigned)nlay;
         const unsigned coff = (unsigned)sizeof(real) * (unsigned)cc;
-        const unsigned voff = (unsigned)sizeof(real) * ((unsigned)(c - (odd ? 1 : 0)) + (odd ? plane : 0u));
+        const unsigned voff = (unsigned)sizeof(real) * ((unsigned)(c - (upper ? 1 : 0)) + (upper ? plane : 0u));
         // running output pointers: (column 0, layer j, g-point 0), advanced by store_pair
         const long plane2 = 2L * plane;
         real *w_tau = Q(t.tau) + (long)ncol * j, *w_ssa = MODE == MODE_SW && t.ssa ? Q(t.ssa) + (long)ncol * j : nullptr;
@@ -574,7 +491,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         constexpr bool FIRST = decltype(first_c)::value;   // blocks of the first layer: the top level too
         constexpr int NPI = (MODE == MODE_LW) ? (FIRST ? 2 * NP2 : NP2) : 0;
         constexpr int NIT = NLI + NBI + NPI;
-        for (int gb = 0; gb < ngp; gb += GC, ob += GC, ol += GC) {
+        for (int gb = 0; gb < ngp; gb += GC) {
           real acc[GC];
           if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
             typedef __attribute__((address_space(1))) const char gcchar;
@@ -593,7 +510,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
             for (int g = 0; g < GC; ++g) acc[g] = real(0);
           }
-          const int pb = L.pl + gb;
+          // (pinned: otherwise the address arithmetic is re-derived per read from the row indices)
+          asm volatile("" : "+v"(ab[0]), "+v"(ab[1]), "+v"(ab[2]), "+v"(ab[3]));
+          asm volatile("" : "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]), "+v"(al[4]), "+v"(al[5]), "+v"(al[6]), "+v"(al[7]));
+          if (MODE == MODE_LW) asm volatile("" : "+v"(ap[0]), "+v"(ap[1]), "+v"(ap[2]), "+v"(ap[3]));
+          if (MODE == MODE_LW && FIRST) asm volatile("" : "+v"(ap[4]), "+v"(ap[5]));
           double2_t buf[2][4];
           real lutp[2] = {real(0), real(0)};
           static_for<0, NIT + 1>([&](auto pos_c) __attribute__((always_inline)) {
@@ -601,25 +522,23 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
             constexpr int it = pos < NIT ? seq_item(pos, NLI, NBI, NPI, NP2) : NIT;    // item read at this position
             // ---------------- issue the reads of item `it` ----------------
             if constexpr (it < NLI) {                       // look_up_table gas: g-points 2*pr, 2*pr+1, vmr plane h
-              const int g = 2 * (it / 2), h = it & 1;
+              constexpr int g = 2 * (it / 2), h = it & 1;
               double2_t *b = buf[pos & 1];
-              const int o = ol + h * dVl + g;
-              b[0] = ld2(o); b[1] = ld2(o + dPl); b[2] = ld2(o + dTl); b[3] = ld2(o + dTl + dPl);
+              b[0] = ld2b(al[4 * h], g); b[1] = ld2b(al[4 * h + 1], g); b[2] = ld2b(al[4 * h + 2], g); b[3] = ld2b(al[4 * h + 3], g);
             } else if constexpr (it < NLI + NBI) {          // one bilinear slot, one g-pair
-              const int s = bil_slot(it - NLI, NB, NP2), g = 2 * bil_pair(it - NLI, NB, NP2);
+              constexpr int so = bil_slot(it - NLI, NB, NP2) * GC + 2 * bil_pair(it - NLI, NB, NP2);
               double2_t *b = buf[pos & 1];
-              const int o = ob + s * ngp + g;
-              b[0] = ld2(o); b[1] = ld2(o + dPb); b[2] = ld2(o + dTb); b[3] = ld2(o + dTb + dPb);
+              b[0] = ld2b(ab[0], so); b[1] = ld2b(ab[1], so); b[2] = ld2b(ab[2], so); b[3] = ld2b(ab[3], so);
             } else if constexpr (it < NIT) {                // Planck sources of one g-pair
               constexpr int k = it - NLI - NBI;
               double2_t *b = buf[pos & 1];
               if constexpr (k < NP2) {                      // layer and level j+1
-                const int g = 2 * k;
-                b[0] = ld2(pb + qlay.off + g); b[1] = ld2(pb + qlay.off + L.SP + g);
-                b[2] = ld2(pb + ql1.off + g);  b[3] = ld2(pb + ql1.off + L.SP + g);
+                constexpr int g = 2 * k;
+                b[0] = ld2b(ap[0], g); b[1] = ld2b(ap[1], g);
+                b[2] = ld2b(ap[2], g); b[3] = ld2b(ap[3], g);
               } else {                                      // first layer: level j
-                const int g = 2 * (k - NP2);
-                b[0] = ld2(pb + ql0.off + g);  b[1] = ld2(pb + ql0.off + L.SP + g);
+                constexpr int g = 2 * (k - NP2);
+                b[0] = ld2b(ap[4], g); b[1] = ld2b(ap[5], g);
               }
             }
             // ---------------- arithmetic of item `it - 1` ----------------
@@ -667,13 +586,13 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair<real>(w_tau, plane2, voff, coff, t0_, t1_, odd, masked, active);
+                        store_pair<real>(w_tau, plane2, voff, coff, t0_, t1_, masked, active);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair<real>(w_ssa, plane2, voff, coff, r0 / t0_, r1 / t1_, odd, masked, active);
-                          store_pair<real>(w_g, plane2, voff, coff, real(0), real(0), odd, masked, active);
+                          store_pair<real>(w_ssa, plane2, voff, coff, r0 / t0_, r1 / t1_, masked, active);
+                          store_pair<real>(w_g, plane2, voff, coff, real(0), real(0), masked, active);
                         }
                       } else {
-                        store_pair<real>(w_tau, plane2, voff, coff, acc[g], acc[g + 1], odd, masked, active);
+                        store_pair<real>(w_tau, plane2, voff, coff, acc[g], acc[g + 1], masked, active);
                       }
                     } else if (gb + g < ng && active) {   // odd ng: last g-point alone
                       const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
@@ -701,10 +620,10 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                     v1[q] = div_pi(ql1.w0 * b[2][q] + ql1.w1 * b[3][q], pi, rpi);
                   }
                   if (both) {
-                    store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], odd, masked, active);
+                    store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], masked, active);
                     if (a.tlev) {                                                    // :423-424
-                      store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
-                      if (has_next) store_pair<real>(w_decn, plane2, voff, coff, v1[0], v1[1], odd, masked, active);
+                      store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], masked, active);
+                      if (has_next) store_pair<real>(w_decn, plane2, voff, coff, v1[0], v1[1], masked, active);
                     }
                   } else if (gb + g < ng && active) {
                     Q(a.lay_source)[o1] = vl[0];
@@ -718,13 +637,19 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int q = 0; q < 2; ++q) v0[q] = div_pi(ql0.w0 * b[0][q] + ql0.w1 * b[1][q], pi, rpi);
                   if (a.tlev) {
-                    if (both) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], odd, masked, active);
+                    if (both) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], masked, active);
                     else if (gb + g < ng && active) Q(a.lev_source_dec)[o1] = v0[0];
                   }
                 }
               }
             }
           });
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ab[q] += cstride;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) al[q] += ES * GC;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ap[q] += ES * GC;
         }
         };
         if (j == 0) {
@@ -759,12 +684,19 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
           for (int s = 0; s < NB; ++s) {
             if (s < t.nbil) {
-              const real *cp = P(t.seq[t.bil_seq[s]].coef) + (long)ng * ((ip0 - 1) + (long)np * (it0 - 1)) + g;
+              const long o00 = (long)ng * ((ip0 - 1) + (long)np * (it0 - 1)) + g;
               const long dP = ng, dT = (long)ng * np;
-              real v = a00 * cp[0];
-              v = fma(a10, cp[dP], v);
-              v = fma(a01, cp[dT], v);
-              v = fma(a11, cp[dT + dP], v);
+              real c00, c10, c01, c11;
+              if (s == t.merge_slot) {
+                c00 = merged_coef(o00); c10 = merged_coef(o00 + dP); c01 = merged_coef(o00 + dT); c11 = merged_coef(o00 + dT + dP);
+              } else {
+                const real *cp = P(t.seq[t.bil_seq[s]].coef) + o00;
+                c00 = cp[0]; c10 = cp[dP]; c01 = cp[dT]; c11 = cp[dT + dP];
+              }
+              real v = a00 * c00;
+              v = fma(a10, c10, v);
+              v = fma(a01, c01, v);
+              v = fma(a11, c11, v);
               if (ANYCLAMP) { v = W[s] * v; v = v < real(0) ? real(0) : v; acc = acc + v; }
               else acc = fma(W[s], v, acc);
             }
@@ -817,6 +749,7 @@ hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
 }
 
 int pick_nb(int nbil) {
+  if (nbil <= 2) return 2;
   if (nbil <= 5) return 5;
   if (nbil <= 7) return 7;
   return kTauPassGases;
@@ -827,6 +760,9 @@ hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp,
   const int ng = a.tau.ng;
   if (anyclamp && ng % 4 == 0) return launch_one<real, 4, kTauPassGases, true, true, MODE>(a, lds, s);
   if (anyclamp) return launch_one<real, 4, kTauPassGases, false, true, MODE>(a, lds, s);
+  if (NBsel == 2 && ng % 8 == 0) return launch_one<real, 8, 2, true, false, MODE>(a, lds, s);
+  if (NBsel == 2 && ng % 4 == 0) return launch_one<real, 4, 2, true, false, MODE>(a, lds, s);
+  if (NBsel == 2) return launch_one<real, 4, 2, false, false, MODE>(a, lds, s);
   if (NBsel == 7 && ng % 8 == 0) return launch_one<real, 8, 7, true, false, MODE>(a, lds, s);
   if (NBsel == 7 && ng % 4 == 0) return launch_one<real, 4, 7, true, false, MODE>(a, lds, s);
   if (NBsel == 5 && ng % 4 == 0) return launch_one<real, 4, 5, true, false, MODE>(a, lds, s);
@@ -843,6 +779,7 @@ hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp,
 void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
   const int nb = pick_nb(nbil);
   if (anyclamp) { *GC = 4; *NB = kTauPassGases; }
+  else if (nb == 2) { *GC = ng % 8 == 0 ? 8 : 4; *NB = 2; }
   else if (nb == 7 && ng % 8 == 0) { *GC = 8; *NB = 7; }
   else if (nb == 7 && ng % 4 == 0) { *GC = 4; *NB = 7; }
   else if (nb == 5) { *GC = 4; *NB = 5; }
@@ -901,6 +838,46 @@ UDiv make_udiv(double d, int f32) {
   return u;
 }
 
+// The gases of a pass whose mole fraction is one number for the whole call: scalar entries of gas_desc (get_vmr
+// broadcasts them, src/gas_optics_ecckd.f90:351) and the none_ composite (:213-221).  Their optical depths are
+//     od_k = simple_weight * m_k * bilinear(coefficient_k),   m_k = vmr_k | vmr_k - reference_k | 1,
+// so their sum is simple_weight * bilinear(sum_k m_k * coefficient_k): one table, one slab slot, four LDS reads and five
+// FMAs per g-point pair instead of that per gas.  The per-gas clamp od_k < 0 -> 0 (:234-238) is kept exactly as long as
+// every od_k of a cell has the sign of simple_weight, i.e. for tables without negative entries and m_k >= 0 -- a gas
+// below its reference concentration, a table with negative entries or a non-finite value keeps its own slot.
+int merge_scalar_gases(TauArgs &t, int f32) {
+  t.merge_slot = -1;
+  t.nmerge = 0;
+  int cand[kMaxSeq], ncand = 0;
+  double mult[kMaxSeq];
+  for (int s = 0; s < t.nbil; ++s) {
+    const SeqGas &e = t.seq[t.bil_seq[s]];
+    if (e.clamp) continue;
+    double m;
+    if (e.code == 0) m = 1.;
+    else if (e.vmr) continue;
+    else if (e.code == 3) m = f32 ? (double)((float)e.scalar - (float)e.ref) : e.scalar - e.ref;
+    else m = f32 ? (double)(float)e.scalar : e.scalar;
+    if (!(m >= 0.) || !(m - m == 0.)) continue;
+    cand[ncand] = t.bil_seq[s];
+    mult[ncand++] = m;
+  }
+  if (ncand < 2) return 0;
+  int keep[kMaxSeq], nkeep = 0;
+  for (int s = 0; s < t.nbil; ++s) {
+    bool merged = false;
+    for (int k = 0; k < ncand; ++k) merged |= cand[k] == t.bil_seq[s];
+    if (!merged) keep[nkeep++] = t.bil_seq[s];
+  }
+  for (int s = 0; s < nkeep; ++s) { t.bil_seq[s] = keep[s]; t.seq[keep[s]].slot = s; }
+  t.merge_slot = nkeep;
+  t.bil_seq[nkeep] = cand[0];   // (never read for the merged slot)
+  t.nbil = nkeep + 1;
+  t.nmerge = ncand;
+  for (int k = 0; k < ncand; ++k) { t.merge_seq[k] = cand[k]; t.merge_mult[k] = mult[k]; t.seq[cand[k]].slot = nkeep; }
+  return ncand;
+}
+
 // Host-side decisions of a fused launch (slots, slab rows, Planck window, grid): everything but the
 // launch itself, so that ecckd_gas_optics_plan() can report them without a GPU.
 hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
@@ -917,7 +894,9 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
     const int k = s < kTauPassGases ? (s < t.nbil ? t.bil_seq[s] : -1) : t.lut;
     SlotArgs &o = a.slot[s];
     o = SlotArgs{t.zero, 0, 0u, 0., 0.};   // unused slot or scalar gas: the load reads a zero word of the model
-    if (k >= 0) {
+    if (s < kTauPassGases && s == t.merge_slot) {
+      o.beta = 1.;                         // the multipliers are in the merged table: weight = simple_weight
+    } else if (k >= 0) {
       const SeqGas &e = t.seq[k];
       const bool arr = e.vmr != nullptr;
       if (arr) {
@@ -968,7 +947,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   if (a.f32 && a.mode != MODE_LW) return hipErrorNotSupported;   // single precision: the longwave fused path only
   plan.lds_bytes = lds;
   plan.anyclamp = anyclamp ? 1 : 0;
-  plan.GC = GC; plan.NB = NB;
+  plan.GC = GC; plan.NB = NB; plan.merged = t.merge_slot >= 0 ? t.nmerge : 0;
   plan.slab_rows = t.R; plan.planck_rows = a.pw; plan.col_chunks = t.col_chunks;
   return hipSuccess;
 }

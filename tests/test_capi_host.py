@@ -184,6 +184,17 @@ def test_launch_plan_host_logic(pkg, oracle_mod, monkeypatch):
     assert (p["col_chunks"] * 60) % 256 == 0            # full rounds of the 256 CUs
     small = k32.plan(100, 60, gases)
     assert small["col_chunks"] == 1
+    # every gas an array: seven bilinear slots, nothing merged; RFMIP's description (well-mixed gases as scalars): the
+    # five of them and the composite share one slot next to o3, and more pressure rows fit
+    assert p["slots"] == 7 and p["merged"] == 0
+    pm = k32.plan(1000000, 60, gases, scalar_gases=["co2", "ch4", "n2o", "o2", "cfc11", "cfc12"])
+    assert pm["slots"] == 2 and pm["merged"] == 6 and pm["slab_rows"] > p["slab_rows"] and pm["g_chunk"] == 8
+    assert k32.plan(1000, 60, gases, scalar_gases=["co2"])["merged"] == 2        # co2 + the composite (o2 is an array: 1.0 * table)
+    pkg.set_solver_option("gas_merge_scalars", 0)
+    try:
+        assert k32.plan(1000, 60, gases, scalar_gases=["co2", "ch4"])["merged"] == 0
+    finally:
+        pkg.set_solver_option("gas_merge_scalars", 1)
     # fp32 halves the table bytes: more pressure rows fit
     assert k32.plan(1000000, 60, gases, single_precision=True)["slab_rows"] > p["slab_rows"]
     # the 36-g file: the whole table does not fit next to 3 rows -> a window of it

@@ -695,3 +695,129 @@ def test_bench_two_ranks_rehearsal(pkg, gpu, tmp_path):
     assert abs(d["value"] - 2 * 60000 * 60 * 32 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL and "REHEARSAL" in d["config"]["parallelism"]
     assert d["roofline"]["kernel"] in ("gas_lw_fused", "rte_lw") and d["cpu_baseline"] is None
+
+
+# ------------------------------------------------------------------------------------------------
+# merged slot: gases passed as one number for the call share one table (gas_merge_scalars)
+# ------------------------------------------------------------------------------------------------
+WELL_MIXED = dict(co2=420e-6, ch4=1.9e-6, n2o=3.3e-7, cfc11=2.3e-10, cfc12=5.2e-10, o2=0.209)
+
+
+@pytest.mark.parametrize("path", [LW_FSCK, LW_RRTMGP])
+def test_merged_scalar_gases_lw(pkg, gpu, oracle_mod, path, monkeypatch):
+    """RFMIP's gas description: well-mixed gases are scalars (mo_rfmip_io.F90 *_GM), h2o and o3 profiles.  The
+    merged table must give the per-gas result: against the oracle (1e-12) and against the unmerged kernel; a
+    column must not depend on the path its wave takes (slab vs tables from global memory)."""
+    k = pkg.GasOpticsEcckd()
+    assert k.load(path, device=0) == ""
+    m = oracle_mod.CkdModel(path)
+    ncol = 1500
+    cols = synthetic.columns(77, ncol, k.get_press_min())
+    plan = k.plan(ncol, 60, synthetic.GAS_ORDER, scalar_gases=list(WELL_MIXED) + ["no2"])
+    assert plan["merged"] == 6 and plan["slots"] == 2
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu, overrides=WELL_MIXED)
+    assert err == ""
+    otau, olay, oinc, odec, osfc, oerr = oracle_mod.gas_optics_int(
+        m, cols["plev"], cols["tlay"], cols["tsfc"], helpers.oracle_gas_items(cols, overrides=WELL_MIXED), cols["tlev"])
+    assert oerr == ""
+    assert helpers.max_rel(tau, otau) < TAU_RTOL
+    assert np.array_equal(lay, olay) and np.array_equal(inc, oinc) and np.array_equal(dec, odec) and np.array_equal(sfc, osfc)
+    pkg.set_solver_option("gas_merge_scalars", 0)
+    try:
+        err, tau0, *_ = helpers.run_lw_gas_optics(pkg, k, cols, gpu, overrides=WELL_MIXED)
+    finally:
+        pkg.set_solver_option("gas_merge_scalars", 1)
+    assert err == "" and helpers.max_rel(tau, tau0) < 1e-13 and not np.array_equal(tau, tau0)
+    # a Planck window of 16 rows sends many waves down the tables-from-global-memory path: same bits
+    monkeypatch.setenv("ECCKD_PLANCK_WINDOW", "16")
+    err, tau_w, *_ = helpers.run_lw_gas_optics(pkg, k, cols, gpu, overrides=WELL_MIXED)
+    monkeypatch.delenv("ECCKD_PLANCK_WINDOW")
+    assert err == "" and np.array_equal(tau_w, tau)
+
+
+def test_merged_scalar_gases_keep_the_per_gas_clamp(pkg, gpu, oracle_mod, lw):
+    """A relative_linear gas below its reference concentration has negative optical depths, which the reference
+    clamps per gas (:234-238): it must stay out of the merged table.  Bottom-up pressure (negative layer
+    thickness) flips every sign: then the gases above their reference are the ones clamped."""
+    k, m = lw
+    ncol = 700
+    cols = synthetic.columns(5, ncol, k.get_press_min())
+    ov = dict(WELL_MIXED, ch4=0.7e-6, n2o=1.0e-7)        # pre-industrial-like: below the reference mole fractions
+    assert k.plan(ncol, 60, synthetic.GAS_ORDER, scalar_gases=list(ov))["merged"] == 6   # (a plan call knows no values)
+    for flip in (False, True):
+        c = dict(cols)
+        if flip:
+            c["plev"] = np.ascontiguousarray(cols["plev"][::-1])
+        err, tau, *_ = helpers.run_lw_gas_optics(pkg, k, c, gpu, overrides=ov)
+        assert err == ""
+        otau, *_rest, oerr = oracle_mod.gas_optics_int(m, c["plev"], c["tlay"], c["tsfc"],
+                                                      helpers.oracle_gas_items(c, overrides=ov), c["tlev"])
+        assert oerr == ""
+        assert np.max(np.abs(tau - otau) / np.maximum(np.abs(otau), 1e-30)) < TAU_RTOL
+        assert np.all(tau >= 0)
+
+
+def test_merged_scalar_gases_sw_and_f32(pkg, gpu, oracle_mod, lw):
+    import torch
+    k = pkg.GasOpticsEcckd()
+    assert k.load(SW_WIDE, device=0) == ""
+    m = oracle_mod.CkdModel(SW_WIDE)
+    ncol, nlay, ng = 900, 60, 27
+    cols = synthetic.columns(3, ncol, k.get_press_min(), shortwave=True)
+    t = T(gpu)
+    names = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
+    gc = helpers.product_gas_concs(pkg, cols, t, names, overrides=WELL_MIXED)
+    op = pkg.OpticalProps2str(); op.alloc_2str(ncol, nlay, k, like=t(np.zeros(1)))
+    toa = torch.empty((ng, ncol), dtype=torch.float64, device=gpu)
+    assert k.gas_optics(None, t(cols["plev"]), t(cols["tlay"]), gc, op, toa) == ""
+    otau, ossa, og, otoa, oerr = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"],
+                                                           helpers.oracle_gas_items(cols, names, overrides=WELL_MIXED))
+    assert oerr == ""
+    assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
+    assert helpers.max_rel(op.ssa.cpu().numpy(), ossa) < TAU_RTOL
+    # single precision, longwave: merged table in fp32 against the fp64 oracle
+    k32, m32 = lw
+    cols = synthetic.columns(11, 1000, k32.get_press_min())
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+    gc = helpers.product_gas_concs(pkg, cols, f, overrides=WELL_MIXED)
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(1000, 60, k32, like=f(np.zeros(1)))
+    src = pkg.SourceFuncLW(); src.alloc(1000, 60, k32, like=f(np.zeros(1)))
+    assert k32.gas_optics(None, f(cols["plev"]), f(cols["tlay"]), f(cols["tsfc"]), gc, op, src, tlev=f(cols["tlev"])) == ""
+    torch.cuda.synchronize()
+    r = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32), dtype=np.float64)
+    c32 = {n: (r(v) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+    ov32 = {n: float(np.float32(v)) for n, v in WELL_MIXED.items()}
+    otau, *_rest, oerr = oracle_mod.gas_optics_int(m32, c32["plev"], c32["tlay"], c32["tsfc"],
+                                                  helpers.oracle_gas_items(c32, overrides=ov32), c32["tlev"])
+    tau32 = op.tau.cpu().numpy().astype(np.float64)
+    big = otau > 1e-6 * otau.max()
+    assert np.max(np.abs(tau32 - otau)[big] / otau[big]) < 2e-5       # as test_single_precision_lw_path
+
+
+def test_planck_sources_entry_point(pkg, gpu, oracle_mod, lw, arithmetic):
+    """ecckd_planck_sources: the four source arrays alone.  Same bits as the sources gas_optics writes (one
+    interpolation code for the fused kernel and the stand-alone one), oracle to 1e-15; without tlev only lay_source and
+    sfc_source are written; ragged column counts."""
+    import torch
+    k, m = lw
+    for ncol in (1, 63, 1000, 1537):
+        cols = synthetic.columns(40, ncol, k.get_press_min())
+        cols["tlay"][5, : min(3, ncol)] = 100.0           # below the Planck table: (T/t0)*B(:,1)
+        cols["tlev"][9, : min(2, ncol)] = 365.0           # above it: linear extrapolation
+        err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+        assert err == ""
+        t = T(gpu)
+        src = pkg.SourceFuncLW(); src.alloc(ncol, 60, k, like=t(np.zeros(1)))
+        for a in (src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source):
+            a.fill_(-1.0)
+        assert k.planck_sources(t(cols["tlay"]), t(cols["tsfc"]), src, tlev=t(cols["tlev"])) == ""
+        torch.cuda.synchronize()
+        for got, want in ((src.lay_source, lay), (src.lev_source_inc, inc), (src.lev_source_dec, dec), (src.sfc_source, sfc)):
+            assert np.array_equal(got.cpu().numpy(), want)
+        olay, oinc, odec, osfc = oracle_mod.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"], [], cols["tlev"])[1:5]
+        for got, want in ((src.lay_source, olay), (src.lev_source_inc, oinc), (src.lev_source_dec, odec), (src.sfc_source, osfc)):
+            assert helpers.max_rel(got.cpu().numpy(), want) < 1e-15
+        src.lev_source_inc.fill_(-1.0); src.lev_source_dec.fill_(-1.0); src.lay_source.fill_(-1.0)
+        assert k.planck_sources(t(cols["tlay"]), t(cols["tsfc"]), src) == ""
+        torch.cuda.synchronize()
+        assert np.array_equal(src.lay_source.cpu().numpy(), lay) and bool((src.lev_source_inc == -1.0).all())

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../rte-ecckd_amd/csrc"
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off"
 mkdir -p ../../variants_tmp /tmp/ecckd_var
-i=0
+i=${VSTART:-0}   # VSTART=2 numbers the variants from v3 (keeps lib_v1/v2 of an earlier source state for the A/B)
 for v in "$@"; do
   i=$((i+1))
   echo "v$i: $v"

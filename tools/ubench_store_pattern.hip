@@ -50,12 +50,14 @@ int main(int argc, char **argv) {
   double *a[4];
   for (int i = 0; i < 4; ++i) { hipMalloc(&a[i], n3 * 8); hipMemset(a[i], 0, n3 * 8); }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto run = [&](const char *name, int mode, int tw, int chunks, int narr) {
+  // lds_bytes of dynamic LDS limit the blocks per CU as the product's slab does (150 KiB: one block = 8 waves per CU)
+  auto run = [&](const char *name, int mode, int tw, int chunks, int narr, int lds_bytes = 0) {
     float best = 1e30f;
+    hipFuncSetAttribute((const void *)pattern<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int rep = 0; rep < 4; ++rep) {
       hipEventRecord(e0);
       dim3 grid(chunks, nlay), blk(512);
-      if (tw == 1) hipLaunchKernelGGL(pattern<1>, grid, blk, 0, 0, a[0], a[1], a[2], a[3], ncol, nlay, ng, mode, narr);
+      if (tw == 1) hipLaunchKernelGGL(pattern<1>, grid, blk, lds_bytes, 0, a[0], a[1], a[2], a[3], ncol, nlay, ng, mode, narr);
       else if (tw == 2) hipLaunchKernelGGL(pattern<2>, grid, blk, 0, 0, a[0], a[1], a[2], a[3], ncol, nlay, ng, mode, narr);
       else if (tw == 4) hipLaunchKernelGGL(pattern<4>, grid, blk, 0, 0, a[0], a[1], a[2], a[3], ncol, nlay, ng, mode, narr);
       else hipLaunchKernelGGL(pattern<8>, grid, blk, 0, 0, a[0], a[1], a[2], a[3], ncol, nlay, ng, mode, narr);
@@ -63,7 +65,8 @@ int main(int argc, char **argv) {
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (rep > 0 && ms < best) best = ms;
     }
-    printf("%-46s chunks %3d arrays %d: %.2f ms  %.2f TB/s\n", name, chunks, narr, best, narr * n3 * 8.0 / (best * 1e-3) / 1e12);
+    printf("%-46s chunks %3d arrays %d lds %3d KiB: %.2f ms  %.2f TB/s\n", name, chunks, narr, lds_bytes / 1024, best,
+           narr * n3 * 8.0 / (best * 1e-3) / 1e12);
   };
   for (int chunks : {64, 128}) {
     run("product order (contiguous tile range per block)", 0, 1, chunks, 4);
@@ -73,5 +76,9 @@ int main(int argc, char **argv) {
     run("8 tiles (32 KiB) per plane visit", 2, 8, chunks, 4);
   }
   run("product order, ONE array (tau only)", 0, 1, 64, 1);
+  // the product's occupancy: blocks per CU limited by LDS
+  run("product order, two blocks per CU", 0, 1, 64, 4, 75 * 1024);
+  run("product order, one block per CU", 0, 1, 64, 4, 150 * 1024);
+  run("ONE array, one block per CU", 0, 1, 64, 1, 150 * 1024);
   return 0;
 }
