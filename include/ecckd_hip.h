@@ -368,7 +368,7 @@ int ecckd_get_arithmetic(void);
  *   "lw_solver"              fp64, 60 layers: 0 register-resident solver (one wave per SIMD), 1 layer-split solver
  *                            (waves of a block share a tile and take 10-15 layers each; three waves per SIMD)
  *   "lw_split_seg"           layers per wave of the layer-split solver: 10 (default), 12 or 15
- *   "gas_merge_scalars"      fast arithmetic mode: 1 (default) the gases of gas_desc given as ONE number for the call
+ *   "gas_merge_scalars"      fast arithmetic mode, fp64: 1 (default) the gases of gas_desc given as ONE number for the call
  *                            (vmr pointer NULL + vmr_scalar; get_vmr broadcasts them, src/gas_optics_ecckd.f90:351) and
  *                            the none_ composite share one table sum_k m_k*coefficient_k, m_k = vmr | vmr - reference | 1,
  *                            built on the fly: tau = ... + simple_weight * bilinear(merged table) instead of one

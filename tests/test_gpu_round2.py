@@ -775,7 +775,7 @@ def test_merged_scalar_gases_sw_and_f32(pkg, gpu, oracle_mod, lw):
     assert oerr == ""
     assert helpers.max_rel(op.tau.cpu().numpy(), otau) < TAU_RTOL
     assert helpers.max_rel(op.ssa.cpu().numpy(), ossa) < TAU_RTOL
-    # single precision, longwave: merged table in fp32 against the fp64 oracle
+    # single precision, longwave, scalar gases (fp32 takes the per-gas path) against the fp64 oracle
     k32, m32 = lw
     cols = synthetic.columns(11, 1000, k32.get_press_min())
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
