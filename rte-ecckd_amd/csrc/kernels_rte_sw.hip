@@ -69,8 +69,13 @@ __device__ __forceinline__ double rcp(double x) {
   r = fma(fma(-x, r, 1.), r, r);
   return r;
 }
-template <bool FAST, bool CLAMP>
-__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq, double mu0, double mu0_inv, double k_floor) {
+// G0: the asymmetry parameter of the whole wave is zero -- what ecCKD's gas optics writes (g = 0, src/gas_optics_ecckd.f90:460);
+// the kernel checks it per layer with a wave vote on the values it has loaded anyway.  With gq a literal 0 the compiler
+// folds (1 - g), 3*mu0*g and the duplicated alpha / k*gamma terms: 12 of ~130 fp64 operations less per cell and pass,
+// every folded operation exact (x*1, x+0), so the same bits as the general form.  Measured -6.7 % on the kernel.
+template <bool FAST, bool CLAMP, bool G0>
+__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq_in, double mu0, double mu0_inv, double k_floor) {
+  const double gq = G0 ? 0. : gq_in;
   const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
   const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
   const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
@@ -172,7 +177,8 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
           const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
           ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
         }
-        const TwoStream ts = two_stream<FAST, CLAMP>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
+        const TwoStream ts = __all(cg == 0.) ? two_stream<FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
+                                             : two_stream<FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
         const double denom = rcp<FAST>(1. - ts.Rdif * albedo);                             // adding, Eq 10
         if (!RECOMPUTE) {
           sA[64L * s] = ts.Tdif * denom;
@@ -225,7 +231,8 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
         }
         double A, B, C, Tn;
         if (RECOMPUTE) {
-          const TwoStream ts = two_stream<FAST, CLAMP>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
+          const TwoStream ts = __all(cg == 0.) ? two_stream<FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
+                                               : two_stream<FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
           const double denom = rcp<FAST>(1. - ts.Rdif * alb_next);     // the same expression as in pass 1: same bits
           A = ts.Tdif * denom; B = ts.Rdif * denom; C = ts.Tdir * denom; Tn = ts.Tnoscat;
         } else {

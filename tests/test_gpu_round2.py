@@ -821,3 +821,29 @@ def test_planck_sources_entry_point(pkg, gpu, oracle_mod, lw, arithmetic):
         assert k.planck_sources(t(cols["tlay"]), t(cols["tsfc"]), src) == ""
         torch.cuda.synchronize()
         assert np.array_equal(src.lay_source.cpu().numpy(), lay) and bool((src.lev_source_inc == -1.0).all())
+
+
+def test_rte_sw_zero_asymmetry_path_is_bit_identical(pkg, gpu):
+    """rte_sw takes a specialised two-stream form for the layers of a wave whose asymmetry parameters are all zero (what
+    ecCKD's gas optics writes).  A column's fluxes must not depend on which form its wave took: the same g = 0 columns,
+    once alone (specialised form) and once next to a column with g != 0 in the same 16-column tile (general form)."""
+    import torch
+    rng = np.random.default_rng(11)
+    ng, nlay, ncol = 27, 60, 64
+    tau = rng.uniform(0.001, 2.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.999, (ng, nlay, ncol))
+    mu0 = rng.uniform(0.05, 1.0, ncol); toa = rng.uniform(10, 100, (ng, ncol)); alb = rng.uniform(0.05, 0.4, (ncol, 1))
+    t = T(gpu)
+    out = []
+    for poison in (False, True):
+        g = np.zeros((ng, nlay, ncol))
+        if poison:
+            g[:, :, 15::16] = 0.3           # the last column of every tile
+        op = pkg.OpticalProps2str(); op.tau, op.ssa, op.g = t(tau), t(ssa), t(g)
+        op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+        fl = pkg.FluxesBroadband(*(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3)))
+        assert pkg.rte_sw(op, True, t(mu0), t(toa), t(alb), t(alb), fl) == ""
+        out.append([f.cpu().numpy() for f in (fl.flux_up, fl.flux_dn, fl.flux_dn_dir)])
+    keep = np.ones(ncol, bool); keep[15::16] = False
+    for a, b in zip(*out):
+        assert np.array_equal(a[:, keep], b[:, keep])
+    assert not np.array_equal(out[0][0][:, ~keep], out[1][0][:, ~keep])     # (the changed columns do change: flux_up)
