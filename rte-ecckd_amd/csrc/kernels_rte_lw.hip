@@ -58,6 +58,14 @@ constexpr int prefetch_depth(int NL) { return NL >= 96 ? 4 : ECCKD_LW_PF; }
 #endif
 constexpr int kSchedSpan = ECCKD_LW_SPAN;   // layers the instruction scheduler may interleave
 
+template <typename real, int CW>
+__device__ __forceinline__ real gsum(real v) {
+  // sum over the lanes that share a column: lane = cl + CW*gs
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
+  return v;
+}
+
 // acc += v by the owner lane (gs == 0) only, as one fire-and-forget ds_add_f64 (an exec-masked
 // read/wait/add/write would expose the full LDS latency twice per layer at one wave per SIMD).
 // The accumulators are double in both precisions: ds_add_f32 retires one lane every 3 clocks on
@@ -74,20 +82,6 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #else
   __hip_atomic_fetch_add(p, owner ? (double)v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #endif
-}
-
-// acc += the wave's g-points of one level, IN G-POINT PAIR ORDER whatever the tile width: the lanes of a column hold
-// GW = 64/CW consecutive g-points; (g, g+1) pairs are summed across lanes (xor CW), then the owner lane adds the pair sums
-// to the accumulator one after the other, lowest g-points first.  With 32 columns per wave (GW = 2) that is one add per
-// step; with 16 (GW = 4) two adds per step and half the steps -- the same additions in the same order, so a column's
-// flux has the same bits whichever tile width its call was given (launch_real picks the width by column count).
-template <typename real, int CW>
-__device__ __forceinline__ void column_add(double *p, real v, bool owner, int cl) {
-  constexpr int GW = 64 / CW;
-  if constexpr (GW >= 2) v = v + __shfl_xor(v, CW);
-  acc_add(p, v, owner);
-#pragma unroll
-  for (int k = 1; k < GW / 2; ++k) acc_add(p, __shfl(v, cl + CW * 2 * k), owner);
 }
 
 template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3>
@@ -228,7 +222,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         asm volatile("" : "+v"(su));
         su_out = su;
         t_out = t;
-        column_add<real, CW>(&acc_dn[(act ? s : nlev) * CW + cl], wfac * I, owner, cl);
+        const real v = gsum<real, CW>(wfac * I);
+        acc_add(&acc_dn[(act ? s : nlev) * CW + cl], v, owner);
         I = t * I + sdn;
       };
       [[maybe_unused]] real carry = bup_first;   // SHARED: far-edge source of the layer above
@@ -260,12 +255,14 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         for (int s = 0; s < kPF; ++s) issue(s, s);
       }
       {
-        column_add<real, CW>(&acc_dn[nlay * CW + cl], wfac * I, owner, cl);
+        const real v = gsum<real, CW>(wfac * I);
+        acc_add(&acc_dn[nlay * CW + cl], v, owner);
       }
       // ---------------- surface + up sweep ----------------
       real U = I * (real(1) - eps) + eps * sfc_src;
       auto up = [&](int s, real t, real su) {
-        column_add<real, CW>(&acc_up[((!PAD || present(s)) ? s + 1 : nlev) * CW + cl], wfac * U, owner, cl);
+        const real v = gsum<real, CW>(wfac * U);
+        acc_add(&acc_up[((!PAD || present(s)) ? s + 1 : nlev) * CW + cl], v, owner);
         U = t * U + su;
       };
 #pragma unroll
@@ -274,7 +271,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         for (int s = nover - 1; s >= 0; --s) up(s, sT[(long)s * 64], sSU[(long)s * 64]);
       }
       {
-        column_add<real, CW>(&acc_up[cl], wfac * U, owner, cl);
+        const real v = gsum<real, CW>(wfac * U);
+        acc_add(&acc_up[cl], v, owner);
       }
     }
 
@@ -313,35 +311,9 @@ hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
                    : launch_ser<real, NL, CW, EXACT, OVER, SHARED, false>(a, s);
 }
 
-// Tile width of the 60-layer variants: 32 columns per wave, or 16 when that fills the chip's wave slots more evenly.
-// The kernel runs one wave per SIMD (4 per CU), so a call is a whole number of rounds of `slots` tiles: 1e5 columns are
-// 3 125 tiles of 32 = 3.05 rounds, i.e. four; as 6 250 tiles of 16 (half as long each) they are 6.1 -> seven half rounds.
-// 16-column tiles read 128-byte instead of 256-byte pieces (taken as 6 % slower per column).  column_add() makes the
-// g-point summation order independent of the width, so the choice does not show in the bits (one quadrature angle;
-// with more the iteration order of (g-point group, angle) differs and the width stays 32).
-// ECCKD_LW_TILE=16|32 forces it (tests).
-int lw_tile_width(const RteLwArgs &a) {
-  static const int forced = getenv("ECCKD_LW_TILE") ? atoi(getenv("ECCKD_LW_TILE")) : 0;
-  if (forced == 16 || forced == 32) return a.nmus == 1 ? forced : 32;
-  if (a.nmus != 1) return 32;
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    slots = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
-                ? 4 * prop.multiProcessorCount : 1024;
-  }
-  auto cost = [&](int cw) {
-    const long tiles = ((long)a.ncol + cw - 1) / cw, rounds = (tiles + slots - 1) / slots;
-    return (double)rounds * cw * (cw == 16 ? 1.06 : 1.0);
-  };
-  return cost(16) < cost(32) ? 16 : 32;
-}
-
 template <typename real, bool SHARED>
 hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
   constexpr int CW = sizeof(real) == 8 ? ECCKD_LW_CW : ECCKD_LW_CW_F32;
-  if (a.nlay == 60 && CW == 32 && lw_tile_width(a) == 16) return launch_one<real, 60, 16, true, false, SHARED>(a, s);
   if (a.nlay == 60) return launch_one<real, 60, CW, true, false, SHARED>(a, s);
   if (a.nlay <= 32) return launch_one<real, 32, CW, false, false, SHARED>(a, s);
   if (a.nlay <= 48) return launch_one<real, 48, CW, false, false, SHARED>(a, s);
