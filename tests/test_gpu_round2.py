@@ -847,3 +847,50 @@ def test_rte_sw_zero_asymmetry_path_is_bit_identical(pkg, gpu):
     for a, b in zip(*out):
         assert np.array_equal(a[:, keep], b[:, keep])
     assert not np.array_equal(out[0][0][:, ~keep], out[1][0][:, ~keep])     # (the changed columns do change: flux_up)
+
+
+def test_merged_scalar_gases_in_a_two_pass_model(pkg, gpu, oracle_mod, lw):
+    """Fourteen gases -> two kernel passes (<= 10 gases each), the second accumulating into tau; most gases are scalars
+    and share the merged slot of their pass; one table has negative entries (its pass takes the per-g-point clamp
+    instantiation and that gas keeps its own slot); orography makes some segments walk several slab positions."""
+    import test_gpu_parity as tp
+    k, m = lw
+    rng = np.random.default_rng(9)
+    tabs = []
+    for n, t in zip(m.gas[:4], m.tables[:4]):
+        tabs.append(dict(name=n, code=t["code"], composite_only=0, mole_fraction=t["mole_fraction"],
+                         reference_mole_fraction=t["reference_mole_fraction"],
+                         coefficient=t["coefficient"] if t["code"] == 2 else t["coefficient"][0]))
+    lin = [t for t in m.tables if t["code"] in (1, 3)]
+    extra = []
+    for i in range(9):
+        src = lin[i % len(lin)]
+        extra.append("x%d" % i)
+        tabs.append(dict(name="x%d" % i, code=1, composite_only=0, mole_fraction=None, reference_mole_fraction=0.0,
+                         coefficient=src["coefficient"][0] * (0.5 + 0.1 * i)))
+    neg = m.tables[2]["coefficient"][0] * rng.choice([1.0, -1.0], size=m.tables[2]["coefficient"][0].shape)
+    tabs.append(dict(name="weird", code=1, composite_only=0, mole_fraction=None, reference_mole_fraction=0.0, coefficient=neg))
+    k2 = pkg.GasOpticsEcckd()
+    assert k2.init_from_tables(m.log_pressure, m.temperature, tabs, planck=(m.temperature_planck, m.planck_function)) == ""
+    m2 = oracle_mod.CkdModel(LW_FSCK)
+    m2.gas = [t["name"] for t in tabs]
+    m2.tables = [dict(code=t["code"], composite_only=False,
+                      mole_fraction=None if t["mole_fraction"] is None else np.ascontiguousarray(t["mole_fraction"], dtype=np.float64),
+                      reference_mole_fraction=t["reference_mole_fraction"],
+                      coefficient=np.ascontiguousarray(t["coefficient"] if t["coefficient"].ndim == 4 else t["coefficient"][None]),
+                      nv=t["coefficient"].shape[0] if t["coefficient"].ndim == 4 else 1) for t in tabs]
+    m2.num_gases = len(tabs)
+    names = [t["name"] for t in tabs]
+    assert len(names) == 14
+    cols = tp.orography_ramp(k.get_press_min(), 1500, c0=21)
+    over = {"weird": 1e-4}
+    over.update({n: 1e-6 * (i + 1) for i, n in enumerate(extra)})
+    over[m.gas[2]] = 4e-4                      # one of the file's own linear gases as a scalar too
+    p = k2.plan(1500, 60, names, scalar_gases=list(over))
+    assert p["passes"] == 2 and p["merged"] >= 6
+    tp.check_lw(pkg, k2, m2, oracle_mod, cols, gpu, names=names, overrides=over)
+    pkg.set_solver_option("gas_merge_scalars", 0)
+    try:
+        tp.check_lw(pkg, k2, m2, oracle_mod, cols, gpu, names=names, overrides=over)
+    finally:
+        pkg.set_solver_option("gas_merge_scalars", 1)
