@@ -12,7 +12,7 @@ P="--cpu-seconds 0 --no-side"
 if [ "$2" != "extra" ]; then
 python bench.py --steps 10 --warmup 2 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -- python3 bench.py --steps 3 --warmup 1 $P > $o/${tag}_bench_prof.json 2> $o/${tag}_bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -- python3 bench.py --steps 10 --warmup 2 $P > $o/${tag}_bench_prof.json 2> $o/${tag}_bench_prof.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $o/${tag}_pmc_$c -- python3 bench.py --steps 2 --warmup 1 $P > /dev/null 2> $o/${tag}_pmc_$c.err
 done
