@@ -24,7 +24,7 @@ echo "lw passes done"
 # ---- SW pair (BASELINE configs[2], 1e5 columns) ----
 S="--mode sw --ncol 100000"
 python bench.py $S --steps 10 --warmup 2 --cpu-seconds 0 > $o/${tag}_bench_sw.json 2> $o/${tag}_bench_sw.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_sw -- python3 bench.py $S --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2> $o/${tag}_prof_sw.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_sw -- python3 bench.py $S --steps 10 --warmup 2 --cpu-seconds 0 > /dev/null 2> $o/${tag}_prof_sw.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $o/${tag}_pmcsw_$c -- python3 bench.py $S --steps 2 --warmup 1 --cpu-seconds 0 > /dev/null 2> $o/${tag}_pmcsw_$c.err
 done
