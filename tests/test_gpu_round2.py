@@ -894,3 +894,49 @@ def test_merged_scalar_gases_in_a_two_pass_model(pkg, gpu, oracle_mod, lw):
         tp.check_lw(pkg, k2, m2, oracle_mod, cols, gpu, names=names, overrides=over)
     finally:
         pkg.set_solver_option("gas_merge_scalars", 1)
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_random_gas_descriptions(pkg, gpu, oracle_mod, lw, arithmetic, seed):
+    """Seeded differential test: a random column count, a random subset and order of the gas list (with unknown names
+    mixed in), every gas in a random one of the four shapes ty_gas_concs knows -- scalar, per-layer profile, per-column
+    value, full array -- some of them below their reference concentration, smooth or rough orography: tau against the
+    oracle at 1e-12, sources bit for bit, in both arithmetic modes.  (Covers the merged slot next to per-gas slots,
+    clamped gases, several slab positions, ragged waves.)"""
+    k, m = lw
+    rng = np.random.default_rng(1000 + seed)
+    ncol = int(rng.choice([1, 17, 64, 65, 333, 512, 700, 1301, 2100]))
+    cols = synthetic.columns(int(rng.integers(0, 10**6)), ncol, k.get_press_min())
+    cols = {kk: (v.copy() if isinstance(v, np.ndarray) else v) for kk, v in cols.items()}
+    if rng.random() < 0.5:                     # orography: smooth ramp or random surface pressure
+        ps = np.linspace(52000.0, 103000.0, ncol) if rng.random() < 0.5 else rng.uniform(52000.0, 103000.0, ncol)
+        eta = (np.arange(61, dtype=np.float64) / 60) ** 2
+        ptop = cols["plev"][0, 0]
+        cols["plev"] = np.ascontiguousarray(ptop + (ps[None, :] - ptop) * eta[:, None])
+    pool = ["co2", "ch4", "n2o", "o2", "n2", "cfc11", "cfc12", "h2o", "o3", "no2", "xyz"]
+    names = [n for n in rng.permutation(pool) if rng.random() < 0.8]
+    base = dict(co2=4e-4, ch4=1.8e-6, n2o=3.3e-7, o2=0.209, n2=0.78, cfc11=2.3e-10, cfc12=5.2e-10, no2=1e-9, xyz=1e-3)
+    over = {}
+    for n in names:
+        if n in ("h2o", "o3"):
+            full = cols[n]
+        else:
+            lo = 0.3 if rng.random() < 0.3 else 1.0        # sometimes below the reference mole fraction
+            full = base[n] * lo * rng.uniform(0.8, 1.6, (60, ncol))
+        shape = rng.integers(0, 4)
+        if shape == 0:
+            over[n] = float(full.mean())
+        elif shape == 1:
+            over[n] = np.ascontiguousarray(full.mean(axis=1))          # (nlay,)
+        elif shape == 2 and ncol != 60:
+            over[n] = np.ascontiguousarray(full.mean(axis=0))          # (ncol,)
+        else:
+            over[n] = np.ascontiguousarray(full)
+    err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu, names=names, overrides=over)
+    assert err == ""
+    otau, olay, oinc, odec, osfc, oerr = oracle_mod.gas_optics_int(
+        m, cols["plev"], cols["tlay"], cols["tsfc"], helpers.oracle_gas_items(cols, names, over), cols["tlev"])
+    assert oerr == ""
+    assert np.array_equal(lay, olay) and np.array_equal(inc, oinc) and np.array_equal(dec, odec) and np.array_equal(sfc, osfc)
+    assert np.max(np.abs(tau - otau) / np.maximum(np.abs(otau), 1e-300)) < TAU_RTOL
+    assert np.array_equal(tau == 0, otau == 0)
