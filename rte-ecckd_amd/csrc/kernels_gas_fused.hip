@@ -493,7 +493,11 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         constexpr int NIT = NLI + NBI + NPI;
         for (int gb = 0; gb < ngp; gb += GC) {
           real acc[GC];
-          if (t.accumulate) {   // second and later passes of a model with more gases than one pass takes
+          // (never in the longwave mode: the Planck sources ride with the FIRST pass only.  Compiled out there, because
+          // with these loads in the chunk loop the compiler keeps an s_waitcnt vmcnt(0) at the join below, at the top of
+          // EVERY chunk, and on the common path that wait is for the previous chunk's stores to be acknowledged:
+          // the stores of a chunk then never overlap the arithmetic of the next.  Found in the disassembly late in round 2.)
+          if (MODE != MODE_LW && t.accumulate) {   // second and later passes of a model with more gases than one pass takes
             typedef __attribute__((address_space(1))) const char gcchar;
             typedef __attribute__((address_space(1))) const real greal;
 #pragma unroll
