@@ -14,10 +14,21 @@
 // RECOMPUTE note at the kernel for what is stored and what is computed twice.
 // (Registers cannot hold it next to a useful occupancy: the coefficient arithmetic is ~250 fp64
 // instructions per cell and needs several waves per SIMD to issue at rate.)
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace ecckd {
 namespace {
+
+// f(integral_constant<int, I>) for I = I0 .. N-1 as straight-line code (compile-time slot indices)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_sw(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_sw<I + 1, N>(f);
+  }
+}
 
 template <int CW>
 __device__ __forceinline__ double gsum(double v) {
@@ -169,13 +180,15 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
         const long q = base + (long)ncol * (lay0 + lstep * sl);
         ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
       }
-      for (int s = nlay - 1; s >= 0; --s) {
-        const double ctau = ptau[0], cssa = pssa[0], cg = pg[0];
-#pragma unroll
-        for (int d = 0; d + 1 < kPF; ++d) { ptau[d] = ptau[d + 1]; pssa[d] = pssa[d + 1]; pg[d] = pg[d + 1]; }
+      // The layer loop is unrolled by the prefetch depth so that every layer has a FIXED slot of the prefetch registers:
+      // shifting the slots along (ptau[d] = ptau[d + 1]) reads registers whose loads are still in flight and made the
+      // compiler wait with vmcnt(0) in every iteration -- one layer of loads in flight instead of kPF (round 2).
+      auto layer1 = [&](int s, auto slot_c) __attribute__((always_inline)) {
+        constexpr int d = decltype(slot_c)::value;
+        const double ctau = ptau[d], cssa = pssa[d], cg = pg[d];
         {
           const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
-          ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
+          ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
         }
         const TwoStream ts = __all(cg == 0.) ? two_stream<FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
                                              : two_stream<FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
@@ -191,6 +204,14 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
         albedo = ts.Rdif + ts.Tdif * ts.Tdif * albedo * denom;                        // Eq 9
         sAlb[64L * s] = albedo;
         sSrc[64L * s] = nsrc;
+      };
+      {
+        int s = nlay - 1;
+        for (; s >= kPF - 1; s -= kPF)                 // whole groups: slot d serves layer s - d
+          static_for_sw<0, kPF>([&](auto dc) __attribute__((always_inline)) { layer1(s - decltype(dc)::value, dc); });
+        static_for_sw<0, kPF>([&](auto dc) __attribute__((always_inline)) {   // the last, partial group
+          if (s - decltype(dc)::value >= 0) layer1(s - decltype(dc)::value, dc);
+        });
       }
 
       // ---- pass 2, top -> bottom: direct beam and fluxes (Eq 12, 13) ----
@@ -213,20 +234,16 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
           ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
         }
       }
-      for (int s = 0; s < nlay; ++s) {
-        const double alb_next = palb[0], nsrc_next = pnsrc[0];
-        const double ctau = ptau[0], cssa = pssa[0], cg = pg[0];
-#pragma unroll
-        for (int d = 0; d + 1 < kPF; ++d) {
-          palb[d] = palb[d + 1]; pnsrc[d] = pnsrc[d + 1];
-          ptau[d] = ptau[d + 1]; pssa[d] = pssa[d + 1]; pg[d] = pg[d + 1];
-        }
+      auto layer2 = [&](int s, auto slot_c) __attribute__((always_inline)) {   // (fixed prefetch slots: see pass 1)
+        constexpr int d = decltype(slot_c)::value;
+        const double alb_next = palb[d], nsrc_next = pnsrc[d];
+        const double ctau = ptau[d], cssa = pssa[d], cg = pg[d];
         {
           const int sn = s + kPF < nlay ? s + kPF : nlay - 1;
-          palb[kPF - 1] = sAlb[64L * (sn + 1)]; pnsrc[kPF - 1] = sSrc[64L * (sn + 1)];
+          palb[d] = sAlb[64L * (sn + 1)]; pnsrc[d] = sSrc[64L * (sn + 1)];
           if (RECOMPUTE) {
             const long q = base + (long)ncol * (lay0 + lstep * sn);
-            ptau[kPF - 1] = a.tau[q]; pssa[kPF - 1] = a.ssa[q]; pg[kPF - 1] = a.g[q];
+            ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
           }
         }
         double A, B, C, Tn;
@@ -247,6 +264,14 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
         acc_add(&acc_up[(s + 1) * CW + cl], vu, owner);
         acc_add(&acc_dn[(s + 1) * CW + cl], vd, owner);
         acc_add(&acc_dir[(s + 1) * CW + cl], vr, owner);
+      };
+      {
+        int s = 0;
+        for (; s + kPF <= nlay; s += kPF)              // whole groups: slot d serves layer s + d
+          static_for_sw<0, kPF>([&](auto dc) __attribute__((always_inline)) { layer2(s + decltype(dc)::value, dc); });
+        static_for_sw<0, kPF>([&](auto dc) __attribute__((always_inline)) {   // the last, partial group
+          if (s + decltype(dc)::value < nlay) layer2(s + decltype(dc)::value, dc);
+        });
       }
     }
 
