@@ -368,6 +368,12 @@ int ecckd_get_arithmetic(void);
  *   "lw_solver"              fp64, 60 layers: 0 register-resident solver (one wave per SIMD), 1 layer-split solver
  *                            (waves of a block share a tile and take 10-15 layers each; three waves per SIMD)
  *   "lw_split_seg"           layers per wave of the layer-split solver: 10 (default), 12 or 15
+ *   "lw_tail_split"          register-resident solver: 1 (default) the tiles beyond the last full round of waves (one
+ *                            wave per SIMD) are solved one g-point pair per wave and summed in g-point order by a
+ *                            second small kernel -- bit-identical fluxes, no idle SIMDs in the last round (1e5 columns:
+ *                            3 125 tiles on 1 024 SIMDs).  Needs up to 64 MiB of stream scratch, taken only when it
+ *                            can be had without an error (not inside a graph capture that has not seen the call
+ *                            before, not beyond a caller-owned buffer): 0 switches it off
  *   "gas_merge_scalars"      fast arithmetic mode, fp64: 1 (default) the gases of gas_desc given as ONE number for the call
  *                            (vmr pointer NULL + vmr_scalar; get_vmr broadcasts them, src/gas_optics_ecckd.f90:351) and
  *                            the none_ composite share one table sum_k m_k*coefficient_k, m_k = vmr | vmr - reference | 1,

@@ -116,6 +116,39 @@ int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
   return 0;
 }
 
+// Same block, for a use the call can do without (the tail split of rte_lw): nullptr instead of an error when the block
+// cannot be provided (caller-owned block too small, stream being captured, allocation refused).
+void *stream_scratch_optional(int device, hipStream_t stream, size_t need) {
+  {
+    ScratchPool &pool = g_scratch_pool[device];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    const auto it = pool.live.find(stream);
+    const bool have = it != pool.live.end() && it->second.bytes >= need;
+    if (!have) {
+      if (it != pool.live.end() && it->second.caller_owned) return nullptr;
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
+    }
+  }
+  void *p = nullptr;
+  if (stream_scratch(device, stream, need, &p)) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+// SIMDs of the device = waves of the register-resident LW solver that run at a time (one wave owns a SIMD)
+int simd_slots(int device) {
+  static std::atomic<int> cached[16];
+  int v = cached[device].load();
+  if (v > 0) return v;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
+  cached[device].store(4 * cus);
+  return 4 * cus;
+}
+
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // Single precision: the *_f32 entry points set this for the duration of the call; every staging
@@ -159,6 +192,7 @@ struct SolverOptions {
   std::atomic<int> lw_split_seg{10};
   // ... and whether the call-constant gases of a pass share one slab slot (merge_scalar_gases(); ~1e-16 relative on tau)
   std::atomic<int> gas_merge_scalars{1};
+  std::atomic<int> lw_tail_split{1};
 };
 SolverOptions g_opt;
 
@@ -490,8 +524,9 @@ int ecckd_set_solver_option(const char *name, double value) {
     if (value != 10. && value != 12. && value != 15.) return fail("ecckd_set_solver_option: lw_split_seg must be 10, 12 or 15");
     g_opt.lw_split_seg.store((int)value);
   } else if (n == "gas_merge_scalars") g_opt.gas_merge_scalars.store(value != 0. ? 1 : 0);
+  else if (n == "lw_tail_split") g_opt.lw_tail_split.store(value != 0. ? 1 : 0);
   else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
-                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars)");
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split)");
   return 0;
 }
 
@@ -506,6 +541,7 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "lw_solver") *value = g_opt.lw_solver.load();
   else if (n == "lw_split_seg") *value = g_opt.lw_split_seg.load();
   else if (n == "gas_merge_scalars") *value = g_opt.gas_merge_scalars.load();
+  else if (n == "lw_tail_split") *value = g_opt.lw_tail_split.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -1082,6 +1118,15 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
     void *sp = nullptr;
     if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
     a.scratch = static_cast<double *>(sp);
+  } else if (g_opt.lw_tail_split.load()) {   // tail tiles one g-pair per wave (rte_lw_tail_plan); optional, same bits
+    long first = -1;
+    const size_t need = ecckd::rte_lw_tail_plan(a, simd_slots(device), &first);
+    if (need) {
+      if (void *sp = stream_scratch_optional(device, launch_stream, need)) {
+        a.partials = static_cast<double *>(sp);
+        a.tail_first = first;
+      }
+    }
   }
   if (memspace == ECCKD_DEVICE) {
     a.tau = tau; a.lay_source = lay_source; a.lev_source_inc = lev_source_inc;

@@ -116,6 +116,9 @@ struct RteLwArgs {
   // implementation choice for fp64 / 60 layers (ecckd_set_solver_option "lw_solver", "lw_split_seg")
   int use_split;               // 1: layer-split solver (kernels_rte_lw_split.hip), 0: register-resident solver
   int split_seg;               // layers per wave of the layer-split solver: 10, 12 or 15
+  // tail split (rte_lw_tail_plan): tiles from tail_first on are solved one g-pair iteration per wave; -1: none
+  long tail_first = -1;
+  double *partials = nullptr;  // [tail tile][iteration][dn, up][nlay+1][columns per tile]
 };
 
 struct RteSwArgs {
@@ -152,6 +155,7 @@ hipError_t launch_sw_gpt(const RteGptArgs &a, hipStream_t s);
 int tau_slab_rows(int ng, int np, int nt, int nbil, int nv_lut);   // R that fits LDS (>= 0)
 size_t tau_lds_bytes(int ng, int np, int nt, int nbil, int nv_lut, int R);
 size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
+size_t rte_lw_tail_plan(const RteLwArgs &a, int slots, long *tail_first);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);

@@ -128,7 +128,19 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   const int niter = ngroups * a.nmus;
   const long ntiles = ((long)ncol + CW - 1) / CW;
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Work units: blocks [0, tail_first) take one whole tile (all g-pairs); beyond that a block takes ONE g-pair
+  // iteration of a tail tile and leaves its sums in `partials` for rte_lw_tail_reduce (see launch_ser).
+  const long tail_first = (OVER || a.tail_first < 0) ? ntiles : a.tail_first;
+  const long nunits = tail_first + (ntiles - tail_first) * niter;
+  for (long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    long tile = unit;
+    int it0 = 0, it1 = niter;
+    if (!OVER && unit >= tail_first) {
+      const long u = unit - tail_first;
+      tile = tail_first + u / niter;
+      it0 = (int)(u - (tile - tail_first) * niter);
+      it1 = it0 + 1;
+    }
     const long col = tile * CW + cl;
     const bool valid = col < ncol;
     const long cc = valid ? col : (long)ncol - 1;
@@ -181,11 +193,11 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       issue(slot, sl);
     };
 
-    pair_start(0);
+    pair_start(it0);
 #pragma unroll
     for (int s = 0; s < kPF; ++s) issue(s, s);
 
-    for (int it = 0; it < niter; ++it) {
+    for (int it = it0; it < it1; ++it) {
       const int gi = it / a.nmus, k = it - gi * a.nmus;
       const int g = gi * GW + gs;
       const bool gact = g < ng;
@@ -249,7 +261,7 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         if (s % kSchedSpan == kSchedSpan - 1) __builtin_amdgcn_sched_barrier(0);
       }
       // the next pair's first register-resident layers start streaming while the up sweep runs
-      if (it + 1 < niter) {
+      if (it + 1 < it1) {
         pair_start(it + 1);
 #pragma unroll
         for (int s = 0; s < kPF; ++s) issue(s, s);
@@ -276,6 +288,13 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       }
     }
 
+    if (!OVER && unit >= tail_first) {   // one g-pair iteration of a tail tile: [unit][dn, up][nlev][CW]
+      double *pp = a.partials + (unit - tail_first) * 2 * nlev * CW;
+      for (int s = gs; s < nlev; s += GW) {
+        pp[s * CW + cl] = acc_dn[s * CW + cl];
+        pp[(nlev + s) * CW + cl] = acc_up[s * CW + cl];
+      }
+    } else
     // broadband fluxes: level s-th from the top -> lev0 + lstep*s
     if (valid) {
       for (int s = gs; s < nlev; s += GW) {
@@ -285,6 +304,29 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
       }
     }
   }
+}
+
+// Sums the per-iteration partial fluxes of the tail tiles in iteration order.  A whole-tile wave adds the value of
+// iteration 0, 1, ... to an accumulator that starts at +0; a tail unit holds 0 + v_it == v_it, so adding the units in
+// the same order reproduces the whole-tile sum bit for bit: whether a column lands in a tail tile does not show.
+template <typename real>
+__global__ void __launch_bounds__(256) rte_lw_tail_reduce(const double *partials, int niter, int nlev, int cw, long tail_first,
+                                                          long ntail, int ncol, long lev0, long lstep, real *flux_dn, real *flux_up) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ntail * nlev * cw) return;
+  const int cl = (int)(idx % cw), s = (int)((idx / cw) % nlev);
+  const long t = idx / ((long)cw * nlev);
+  const long col = (tail_first + t) * cw + cl;
+  if (col >= ncol) return;
+  const double *p = partials + (t * niter * 2 * nlev + s) * cw + cl;
+  double dn = 0., up = 0.;
+  for (int it = 0; it < niter; ++it, p += 2L * nlev * cw) {
+    dn += p[0];
+    up += p[(long)nlev * cw];
+  }
+  const long q = col + (long)ncol * (lev0 + lstep * s);
+  flux_dn[q] = (real)dn;
+  flux_up[q] = (real)up;
 }
 
 constexpr int kOverWaves = 2048;   // grid of the overflow variant (its scratch ring is per wave)
@@ -301,7 +343,17 @@ hipError_t launch_ser(const RteLwArgs &a, hipStream_t s) {
   if (e != hipSuccess) return e;
   long tiles = ((long)a.ncol + CW - 1) / CW;
   if (OVER && tiles > kOverWaves) tiles = kOverWaves;
-  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
+  const long ntail = (!OVER && a.tail_first >= 0) ? tiles - a.tail_first : 0;
+  const int niter = ((a.ng + 64 / CW - 1) / (64 / CW)) * a.nmus;
+  const long blocks = tiles - ntail + ntail * niter;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, s, a);
+  e = hipGetLastError();
+  if (e != hipSuccess || ntail == 0) return e;
+  const int nlev = a.nlay + 1;
+  const long n = ntail * nlev * CW;
+  const long lev0 = a.top_at_1 ? 0 : a.nlay, lstep = a.top_at_1 ? 1 : -1;
+  hipLaunchKernelGGL(rte_lw_tail_reduce<real>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partials, niter, nlev, CW,
+                     a.tail_first, ntail, a.ncol, lev0, lstep, reinterpret_cast<real *>(a.flux_dn), reinterpret_cast<real *>(a.flux_up));
   return hipGetLastError();
 }
 
@@ -324,6 +376,31 @@ hipError_t launch_real(const RteLwArgs &a, hipStream_t s) {
 }
 
 }  // namespace
+
+// Tail split of the register-resident solver.  A wave owns a SIMD (512 registers), so `slots` tiles run at a time and
+// the tiles beyond the last full round keep a fraction of the SIMDs busy for a whole tile time (1e5 columns: 3 125
+// tiles on 1 024 SIMDs, the 4th round holds 53).  When that costs more than kTailGain of the call, the tail tiles are
+// handed out one g-pair iteration per wave instead (53 x 16 units, one sixteenth of a round) and summed by
+// rte_lw_tail_reduce, with the same bits.  Returns the bytes of `partials` the split needs (0: no split) and the first
+// tail tile; the caller sets a.tail_first / a.partials when it can provide them and leaves tail_first = -1 otherwise.
+size_t rte_lw_tail_plan(const RteLwArgs &a, int slots, long *tail_first) {
+  constexpr double kTailGain = 0.03;
+  constexpr size_t kTailMaxBytes = (size_t)64 << 20;
+  *tail_first = -1;
+  if (a.ncol <= 0 || a.nlay > kMaxRegisterLayers || slots <= 0) return 0;
+  if (a.use_split && rte_lw_split_applies(a)) return 0;
+  const int cw = a.f32 ? ECCKD_LW_CW_F32 : ECCKD_LW_CW, gw = 64 / cw;
+  const long niter = (long)((a.ng + gw - 1) / gw) * a.nmus;
+  const long tiles = ((long)a.ncol + cw - 1) / cw, full = tiles / slots * slots, ntail = tiles - full;
+  if (ntail == 0 || niter < 2) return 0;
+  const double before = (double)(full / slots + 1);
+  const double after = (double)(full / slots) + (double)((ntail * niter + slots - 1) / slots) / (double)niter;
+  if (before - after < kTailGain * before) return 0;
+  const size_t bytes = sizeof(double) * 2 * (size_t)(a.nlay + 1) * cw * (size_t)(ntail * niter);
+  if (bytes > kTailMaxBytes) return 0;
+  *tail_first = full;
+  return bytes;
+}
 
 size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng) {
   (void)ng;

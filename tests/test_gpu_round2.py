@@ -984,3 +984,52 @@ def test_random_sw_gas_descriptions_and_fluxes(pkg, gpu, oracle_mod, seed):
     # direct terms amplify that, up to ~1e-9 W m-2 here; the solver-only tests feed both sides the same arrays)
     for got, want in ((fl.flux_up, fu), (fl.flux_dn, fd), (fl.flux_dn_dir, fdir)):
         assert np.max(np.abs(got.cpu().numpy() - want)) < 10 * FLUX_ATOL
+
+
+# tail split of the register-resident LW solver ("lw_tail_split"): tail tiles one g-point pair per wave + ordered sum
+@pytest.mark.parametrize("ncol,nlay,ng,nmus,top_at_1,f32,shared", [
+    (1000, 60, 32, 1, True, False, False),      # fewer tiles than SIMDs: every tile is a tail tile
+    (33000, 60, 32, 1, True, False, True),      # one full round of 1 024 tiles + 8 tail tiles (the last one partly empty)
+    (33000, 60, 32, 1, False, True, False),     # single precision
+    (2500, 40, 27, 3, False, False, False),     # padded variant, odd g-point count, three angles
+    (700, 91, 16, 2, True, False, True),
+    (300, 137, 8, 1, True, False, False),       # beyond 96 layers: overflow variant, no split (option has no effect)
+])
+def test_rte_lw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, nmus, top_at_1, f32, shared):
+    """Fluxes with the tail split (default) against the whole-tile waves of round 1: the same bits, with and without
+    incident flux.  The split sums the g-pair contributions in the order the whole-tile wave adds them."""
+    import torch
+    rng = np.random.default_rng(ncol + nlay)
+    dt = torch.float32 if f32 else torch.float64
+    tau = rng.uniform(0, 2, (ng, nlay, ncol)) * rng.choice([1e-9, 1e-3, 1.0], size=(ng, nlay, ncol))
+    lay = rng.uniform(1, 9, (ng, nlay, ncol))
+    lev = rng.uniform(1, 9, (ng, nlay + 1, ncol))
+    inc, dec = np.ascontiguousarray(lev[:, 1:]), np.ascontiguousarray(lev[:, :-1])
+    sfc = rng.uniform(1, 9, (ng, ncol))
+    emis = rng.uniform(0.7, 1.0, (ncol, 2))
+    incf = rng.uniform(0, 3, (ng, ncol))
+    half = ng // 2
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu).to(dt)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = np.array([[1, half], [half + 1, ng]], dtype=np.int32)
+    src = pkg.SourceFuncLW()
+    src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    emis_d, incf_d = t(emis), t(incf)
+    out = {}
+    incs = (False,) if (f32 or shared) else (False, True)   # inc_flux: fp64, generic solver
+    try:
+        for split in (1, 0):
+            pkg.set_solver_option("lw_tail_split", split)
+            for with_inc in incs:
+                fl = pkg.FluxesBroadband(torch.full((nlay + 1, ncol), -1., dtype=dt, device=gpu),
+                                         torch.full((nlay + 1, ncol), -1., dtype=dt, device=gpu))
+                kw = dict(inc_flux=incf_d) if with_inc else {}
+                assert pkg.rte_lw(op, top_at_1, src, emis_d, fl, n_gauss_angles=nmus, shared_levels=shared, **kw) == ""
+                out[split, with_inc] = (fl.flux_up.cpu().numpy(), fl.flux_dn.cpu().numpy())
+    finally:
+        pkg.set_solver_option("lw_tail_split", 1)
+    for with_inc in incs:
+        assert np.array_equal(out[1, with_inc][0], out[0, with_inc][0])
+        assert np.array_equal(out[1, with_inc][1], out[0, with_inc][1])
+        assert np.all(out[1, with_inc][0] > 0)
+    if len(incs) == 2:
+        assert not np.array_equal(out[1, True][1], out[1, False][1])
