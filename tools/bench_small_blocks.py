@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Small column blocks (the reference driver uses blocks of ONE column, ecckd_rfmip_lw.F90:39): gas_optics +
-rte_lw, direct calls against replaying a captured HIP graph.  Finding: a step takes ~255 us whatever the block
-size up to ~512 columns and however it is launched -- the floor is the serial depth of one wave of rte_lw
-(16 g-point groups x 60 layers x two sweeps), not launch overhead; blocks should hold >= 32k columns.
+rte_lw, direct calls against replaying a captured HIP graph, and the same with whole-tile solver waves only
+(lw_tail_split = 0).  Finding: 68 us for 1-64 columns however it is launched (258 us without the tail split: the
+serial depth of one wave of rte_lw, 16 g-point groups x 60 layers x two sweeps); blocks should hold >= 32k columns.
 Usage: python tools/bench_small_blocks.py"""
 import os
 import sys
@@ -21,7 +21,7 @@ assert k.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
                            "ecckd-1.2_lw_ckd-definition_climate_fsck-tol0.0161.nc"), device=0) == ""
 nlay, ng = 60, k.get_ngpt()
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-for ncol in (1, 64, 512, 4096):
+for ncol in (1, 64, 512, 4096, 16384):
     cols = synthetic.columns(0, ncol, k.get_press_min())
     gc = pkg.GasConcs(synthetic.GAS_ORDER)
     for n in synthetic.GAS_ORDER:
@@ -50,7 +50,7 @@ for ncol in (1, 64, 512, 4096):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):   # the stream of the warm-up call: its scratch block exists (tail split)
         step()
     reps = 200
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -61,5 +61,11 @@ for ncol in (1, 64, 512, 4096):
     for _ in range(reps):
         graph.replay()
     torch.cuda.synchronize(); replay = (time.perf_counter() - t0) / reps
-    print("ncol %5d: direct calls (Python mirror) %7.1f us/step, graph replay %7.1f us/step  (%.1f Mcell/s replayed)"
-          % (ncol, direct * 1e6, replay * 1e6, ncol * nlay * ng / replay / 1e6), flush=True)
+    pkg.set_solver_option("lw_tail_split", 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize(); whole = (time.perf_counter() - t0) / reps
+    pkg.set_solver_option("lw_tail_split", 1)
+    print("ncol %5d: direct calls (Python mirror) %7.1f us/step, graph replay %7.1f us/step  (%.1f Mcell/s replayed); direct calls with lw_tail_split = 0: %7.1f us/step"
+          % (ncol, direct * 1e6, replay * 1e6, ncol * nlay * ng / replay / 1e6, whole * 1e6), flush=True)
