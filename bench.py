@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--mode", choices=["lw", "sw"], default="lw",
                     help="lw = headline metric; sw = secondary line (BASELINE configs[2]: gas_optics + rte_sw)")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling passes)")
+    ap.add_argument("--solver-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="ecckd_set_solver_option before the run (A/B of implementation choices, e.g. lw_tail_split=0)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the process group is gloo "
                          "(RCCL cannot put two ranks on one device).  Exercises the rank/column-range/barrier/MAX/gather "
@@ -330,6 +332,9 @@ def main():
     lw_file = LW_FILE if args.lut == "fsck" else LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061")
     L = pkg.lib()
     pkg.set_arithmetic(pkg.FAST if args.arithmetic == "fast" else pkg.REFERENCE_ORDER)
+    for item in args.solver_option:
+        name, _, value = item.partition("=")
+        pkg.set_solver_option(name, float(value))
     k = pkg.GasOpticsEcckd()
     err = k.load(lw_file, device=local_rank)
     if err:
@@ -636,6 +641,9 @@ def main_sw(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     L = pkg.lib()
+    for item in args.solver_option:
+        name, _, value = item.partition("=")
+        pkg.set_solver_option(name, float(value))
     k = pkg.GasOpticsEcckd()
     err = k.load(sw_file, device=0)
     if err:

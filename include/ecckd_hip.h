@@ -374,6 +374,9 @@ int ecckd_get_arithmetic(void);
  *                            3 125 tiles on 1 024 SIMDs).  Needs up to 64 MiB of stream scratch, taken only when it
  *                            can be had without an error (not inside a graph capture that has not seen the call
  *                            before, not beyond a caller-owned buffer): 0 switches it off
+ *   "sw_tail_split"          the same for rte_sw (persistent grid of three waves per SIMD; one g-point group per wave),
+ *                            applied to calls that do not fill one round of waves (< 49 152 columns; it gains nothing
+ *                            beyond): 1 (default), 0 off; bit-identical fluxes
  *   "gas_merge_scalars"      fast arithmetic mode, fp64: 1 (default) the gases of gas_desc given as ONE number for the call
  *                            (vmr pointer NULL + vmr_scalar; get_vmr broadcasts them, src/gas_optics_ecckd.f90:351) and
  *                            the none_ composite share one table sum_k m_k*coefficient_k, m_k = vmr | vmr - reference | 1,

@@ -193,6 +193,7 @@ struct SolverOptions {
   // ... and whether the call-constant gases of a pass share one slab slot (merge_scalar_gases(); ~1e-16 relative on tau)
   std::atomic<int> gas_merge_scalars{1};
   std::atomic<int> lw_tail_split{1};
+  std::atomic<int> sw_tail_split{1};
 };
 SolverOptions g_opt;
 
@@ -525,8 +526,9 @@ int ecckd_set_solver_option(const char *name, double value) {
     g_opt.lw_split_seg.store((int)value);
   } else if (n == "gas_merge_scalars") g_opt.gas_merge_scalars.store(value != 0. ? 1 : 0);
   else if (n == "lw_tail_split") g_opt.lw_tail_split.store(value != 0. ? 1 : 0);
+  else if (n == "sw_tail_split") g_opt.sw_tail_split.store(value != 0. ? 1 : 0);
   else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
-                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split)");
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split, sw_tail_split)");
   return 0;
 }
 
@@ -542,6 +544,7 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "lw_split_seg") *value = g_opt.lw_split_seg.load();
   else if (n == "gas_merge_scalars") *value = g_opt.gas_merge_scalars.load();
   else if (n == "lw_tail_split") *value = g_opt.lw_tail_split.load();
+  else if (n == "sw_tail_split") *value = g_opt.sw_tail_split.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -1232,7 +1235,19 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
   const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
-  if (scratch) {   // stream-ordered scratch ring, no synchronisation (see ScratchPool)
+  if (g_opt.sw_tail_split.load()) {   // tail tiles one g-point group per wave (rte_sw_tail_plan); optional, same bits
+    long first = -1;
+    size_t partials_at = 0;
+    const size_t need = ecckd::rte_sw_tail_plan(a, &first, &partials_at);
+    if (need) {
+      if (void *sp = stream_scratch_optional(device, launch_stream, need > scratch ? need : scratch)) {
+        a.scratch = static_cast<double *>(sp);
+        a.partials = reinterpret_cast<double *>(static_cast<char *>(sp) + partials_at);
+        a.tail_first = first;
+      }
+    }
+  }
+  if (scratch && a.tail_first < 0) {   // stream-ordered scratch ring, no synchronisation (see ScratchPool)
     void *sp = nullptr;
     if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
     a.scratch = static_cast<double *>(sp);

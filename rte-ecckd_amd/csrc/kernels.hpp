@@ -133,6 +133,9 @@ struct RteSwArgs {
   // version switches (ecckd_set_solver_option)
   double k_floor;              // lower bound of (gamma1-gamma2)(gamma1+gamma2) under the square root (1e-12)
   int dir_clamp;               // 1: Rdir/Tdir energy clamps of later RTE-RRTMGP releases
+  // tail split (rte_sw_tail_plan): tiles from tail_first on are solved one g-point group per wave; -1: none
+  long tail_first = -1;
+  double *partials = nullptr;  // [tail tile][group][up, dn, dir][nlay+1][columns per tile]
 };
 
 // Spectral-output solvers (kernels_rte_gpt.hip): RTE-RRTMGP's kernel-level interfaces.  LW uses tau, lay_source,
@@ -157,6 +160,7 @@ size_t tau_lds_bytes(int ng, int np, int nt, int nbil, int nv_lut, int R);
 size_t rte_lw_scratch_bytes(int ncol, int nlay, int ng);
 size_t rte_lw_tail_plan(const RteLwArgs &a, int slots, long *tail_first);
 size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng);
+size_t rte_sw_tail_plan(const RteSwArgs &a, long *tail_first, size_t *partials_at);
 
 hipError_t launch_tau(TauArgs &a, hipStream_t s);
 // What prepare_gas_fused() decided for one pass.

@@ -147,7 +147,19 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
   const long ntiles = ((long)ncol + CW - 1) / CW;
   const double k_floor = a.k_floor;
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Work units (see rte_sw_tail_plan): units [0, tail_first) are whole tiles; beyond that a unit is ONE g-point group
+  // of a tail tile and leaves its sums in `partials` for rte_sw_tail_reduce.
+  const long tail_first = a.tail_first < 0 ? ntiles : a.tail_first;
+  const long nunits = tail_first + (ntiles - tail_first) * ngroups;
+  for (long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    long tile = unit;
+    int g0 = 0, g1 = ngroups;
+    if (unit >= tail_first) {
+      const long u = unit - tail_first;
+      tile = tail_first + u / ngroups;
+      g0 = (int)(u - (tile - tail_first) * ngroups);
+      g1 = g0 + 1;
+    }
     const long col = tile * CW + cl;
     const bool valid = col < ncol;
     const long cc = valid ? col : (long)ncol - 1;
@@ -155,7 +167,7 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
     const double mu0 = a.mu0[cc];
     const double mu0_inv = 1. / mu0;
 
-    for (int gi = 0; gi < ngroups; ++gi) {
+    for (int gi = g0; gi < g1; ++gi) {
       const int g = gi * GW + gs;
       const bool gact = g < ng;
       const int gg = gact ? g : ng - 1;
@@ -275,7 +287,14 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
       }
     }
 
-    if (valid) {
+    if (unit >= tail_first) {   // one g-point group of a tail tile: [unit][up, dn, dir][nlev][CW]
+      double *pp = a.partials + (unit - tail_first) * 3 * nlev * CW;
+      for (int s = gs; s < nlev; s += GW) {
+        pp[s * CW + cl] = acc_up[s * CW + cl];
+        pp[(nlev + s) * CW + cl] = acc_dn[s * CW + cl];
+        pp[(2 * nlev + s) * CW + cl] = acc_dir[s * CW + cl];
+      }
+    } else if (valid) {
       for (int s = gs; s < nlev; s += GW) {
         const long q = col + (long)ncol * (lev0 + lstep * s);
         a.flux_up[q] = acc_up[s * CW + cl];
@@ -284,6 +303,30 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
       }
     }
   }
+}
+
+// Sums the per-group partial fluxes of the tail tiles in group order: the order in which a whole-tile wave adds the
+// same values to accumulators that start at +0, hence the same bits (see rte_lw_tail_reduce, kernels_rte_lw.hip).
+__global__ void __launch_bounds__(256) rte_sw_tail_reduce(const double *partials, int ngroups, int nlev, int cw, long tail_first,
+                                                          long ntail, int ncol, long lev0, long lstep, double *flux_up,
+                                                          double *flux_dn, double *flux_dir) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ntail * nlev * cw) return;
+  const int cl = (int)(idx % cw), s = (int)((idx / cw) % nlev);
+  const long t = idx / ((long)cw * nlev);
+  const long col = (tail_first + t) * cw + cl;
+  if (col >= ncol) return;
+  const double *p = partials + (t * ngroups * 3 * nlev + s) * cw + cl;
+  double up = 0., dn = 0., dir = 0.;
+  for (int gi = 0; gi < ngroups; ++gi, p += 3L * nlev * cw) {
+    up += p[0];
+    dn += p[(long)nlev * cw];
+    dir += p[2L * nlev * cw];
+  }
+  const long q = col + (long)ncol * (lev0 + lstep * s);
+  flux_up[q] = up;
+  flux_dn[q] = dn;
+  if (flux_dir) flux_dir[q] = dir;
 }
 
 __global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *toa) {
@@ -310,6 +353,41 @@ size_t rte_sw_scratch_bytes(int ncol, int nlay, int ng) {
   return sizeof(double) * (size_t)((kSwRecompute ? 0L : 4L) * nlay + 2L * (nlay + 1)) * 64 * (size_t)tiles;
 }
 
+namespace {
+size_t sw_ring_bytes(int nlay, long blocks) {
+  return sizeof(double) * (size_t)((kSwRecompute ? 0L : 4L) * nlay + 2L * (nlay + 1)) * 64 * (size_t)blocks;
+}
+}  // namespace
+
+// Tail split of rte_sw, as rte_lw_tail_plan (kernels_rte_lw.hip): the grid is persistent (kSwWaves blocks, three per
+// SIMD); the tiles of a call that does not fill one round are handed out one g-point group per wave.  Returns the bytes the split
+// needs in all -- the scratch ring of the (possibly larger) grid, then the partial sums at offset *partials_at -- or 0.
+size_t rte_sw_tail_plan(const RteSwArgs &a, long *tail_first, size_t *partials_at) {
+  constexpr double kTailGain = 0.03;
+  constexpr size_t kTailMaxBytes = (size_t)64 << 20;
+  *tail_first = -1;
+  *partials_at = 0;
+  if (a.ncol <= 0) return 0;
+  constexpr int CW = ECCKD_SW_CW, GW = 64 / CW;
+  const long ngroups = (a.ng + GW - 1) / GW;
+  const long tiles = ((long)a.ncol + CW - 1) / CW, full = tiles / kSwWaves * kSwWaves, ntail = tiles - full;
+  if (ntail == 0 || ngroups < 2) return 0;
+  // Only calls of less than one round: with three waves per SIMD a part-empty last round costs next to nothing (the
+  // waves left on a SIMD run faster: 100 000 columns 3.36 against 3.39 ms with and without the split, 50 000 columns
+  // 1.85 against 1.81), while a small call gains the factor the groups run side by side (1 000 columns: 0.43 -> 0.08 ms).
+  if (full > 0) return 0;
+  const double before = (double)(full / kSwWaves + 1);
+  const double after = (double)(full / kSwWaves) + (double)((ntail * ngroups + kSwWaves - 1) / kSwWaves) / (double)ngroups;
+  if (before - after < kTailGain * before) return 0;
+  const size_t part = sizeof(double) * 3 * (size_t)(a.nlay + 1) * CW * (size_t)(ntail * ngroups);
+  if (part > kTailMaxBytes) return 0;
+  long blocks = full + ntail * ngroups;
+  if (blocks > kSwWaves) blocks = kSwWaves;
+  *tail_first = full;
+  *partials_at = (sw_ring_bytes(a.nlay, blocks) + 255) & ~(size_t)255;
+  return *partials_at + part;
+}
+
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
   constexpr int CW = ECCKD_SW_CW;
@@ -320,9 +398,19 @@ hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  long tiles = ((long)a.ncol + CW - 1) / CW;
-  if (tiles > kSwWaves) tiles = kSwWaves;
-  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(64), lds, s, a);
+  const long tiles = ((long)a.ncol + CW - 1) / CW;
+  const long ntail = a.tail_first >= 0 ? tiles - a.tail_first : 0;
+  const int ngroups = (a.ng + 64 / CW - 1) / (64 / CW);
+  long blocks = tiles - ntail + ntail * ngroups;
+  if (blocks > kSwWaves) blocks = kSwWaves;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, s, a);
+  e = hipGetLastError();
+  if (e != hipSuccess || ntail == 0) return e;
+  const int nlev = a.nlay + 1;
+  const long n = ntail * nlev * CW;
+  const long lev0 = a.top_at_1 ? 0 : a.nlay, lstep = a.top_at_1 ? 1 : -1;
+  hipLaunchKernelGGL(rte_sw_tail_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partials, ngroups, nlev, CW,
+                     a.tail_first, ntail, a.ncol, lev0, lstep, a.flux_up, a.flux_dn, a.flux_dir);
   return hipGetLastError();
 }
 

@@ -1033,3 +1033,42 @@ def test_rte_lw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, nmus, top_
         assert np.all(out[1, with_inc][0] > 0)
     if len(incs) == 2:
         assert not np.array_equal(out[1, True][1], out[1, False][1])
+
+
+@pytest.mark.parametrize("ncol,nlay,ng,top_at_1,clamp", [
+    (500, 60, 27, True, 0),       # fewer tiles than resident waves: every tile is a tail tile
+    (50000, 60, 27, True, 0),     # one full round of 3 072 tiles + 53 tail tiles: no split beyond one round (option without effect)
+    (9000, 60, 27, False, 0),     # 563 tiles: the largest calls that still split (partial sums below 64 MiB)
+    (1003, 37, 14, False, 1),     # other layer count, bottom-up arrays, partly empty last tile and last g-point group
+])
+def test_rte_sw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, top_at_1, clamp):
+    """rte_sw with the tail split ("sw_tail_split", default) against whole-tile waves: the same bits in flux_up,
+    flux_dn and flux_dn_dir, in both arithmetic modes."""
+    import torch
+    rng = np.random.default_rng(ncol)
+    tau = rng.uniform(0.001, 2.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.999, (ng, nlay, ncol))
+    g = rng.uniform(0.0, 0.8, (ng, nlay, ncol)) * (rng.uniform(size=(1, 1, ncol)) < 0.5)
+    mu0 = rng.uniform(0.05, 1.0, ncol); toa = rng.uniform(10, 100, (ng, ncol))
+    albd, albf = rng.uniform(0.05, 0.4, (ncol, 2)), rng.uniform(0.05, 0.4, (ncol, 2))
+    half = ng // 2
+    t = T(gpu)
+    op = pkg.OpticalProps2str(); op.tau, op.ssa, op.g = t(tau), t(ssa), t(g)
+    op.band2gpt = np.array([[1, half], [half + 1, ng]], dtype=np.int32)
+    args = (t(mu0), t(toa), t(albd), t(albf))
+    pkg.set_solver_option("sw_dir_clamp", clamp)
+    try:
+        for arith in (0, 1):   # fast, reference expression order
+            pkg.set_arithmetic(arith)
+            out = []
+            for split in (1, 0):
+                pkg.set_solver_option("sw_tail_split", split)
+                fl = pkg.FluxesBroadband(*(torch.full((nlay + 1, ncol), -1., dtype=torch.float64, device=gpu) for _ in range(3)))
+                assert pkg.rte_sw(op, top_at_1, *args, fl) == ""
+                out.append([f.cpu().numpy() for f in (fl.flux_up, fl.flux_dn, fl.flux_dn_dir)])
+            for a, b in zip(*out):
+                assert np.array_equal(a, b)
+            assert np.all(out[0][1] >= 0) and np.all(out[0][0] >= 0)
+    finally:
+        pkg.set_arithmetic(0)
+        pkg.set_solver_option("sw_tail_split", 1)
+        pkg.set_solver_option("sw_dir_clamp", 0)
