@@ -25,7 +25,7 @@ program ecckd_driver
   use mo_optical_props, only: ty_optical_props_1scl, ty_optical_props_2str
   use mo_ecckd_device, only: ty_optical_props_1scl_dev, ty_optical_props_2str_dev, ty_source_func_lw_dev
   use mo_rte_kind, only: wp
-  use mo_rte_lw, only: rte_lw
+  use mo_rte_lw, only: rte_lw, rte_set_solver_option
   use mo_rte_sw, only: rte_sw
   use mo_source_functions, only: ty_source_func_lw
   implicit none
@@ -55,6 +55,15 @@ program ecckd_driver
   if (command_argument_count() < 4) then
     write(error_unit, *) "usage: ecckd_driver lw|sw ecckd_file input.bin output.bin [block_size] [n_quad_angles]"
     stop 1
+  end if
+  ! ECCKD_SOLVER_OPTION=name=value in the environment: one solver option set through the Fortran binding
+  call get_environment_variable("ECCKD_SOLVER_OPTION", arg, status=i)
+  if (i == 0 .and. len_trim(arg) > 0) then
+    u = index(arg, "=")
+    if (u < 2) call stop_on_err("ecckd_driver: ECCKD_SOLVER_OPTION must be name=value")
+    read(arg(u + 1:), *, iostat=i) secs
+    if (i /= 0) call stop_on_err("ecckd_driver: ECCKD_SOLVER_OPTION must be name=value")
+    call stop_on_err(rte_set_solver_option(arg(1:u - 1), secs))
   end if
   call get_command_argument(1, mode)
   call get_command_argument(2, ecckd_path)

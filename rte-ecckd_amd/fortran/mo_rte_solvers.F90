@@ -20,8 +20,17 @@ module mo_rte_lw
   use gas_optics_ecckd, only: c_error_message, c_loc_3d, c_loc_2d
   implicit none
   private
-  public :: rte_lw
+  public :: rte_lw, rte_set_solver_option
   interface
+    ! version switches of the un-pinned RTE-RRTMGP solvers and implementation choices (include/ecckd_hip.h:
+    ! ecckd_set_solver_option): "lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor",
+    ! "sw_dir_clamp", "lw_solver", "lw_split_seg", "gas_merge_scalars", "lw_tail_split", "sw_tail_split"
+    function c_set_solver_option(name, value) bind(C, name="ecckd_set_solver_option") result(rc)
+      import c_int, c_double, c_char
+      character(kind=c_char), dimension(*), intent(in) :: name
+      real(c_double), value :: value
+      integer(c_int) :: rc
+    end function c_set_solver_option
     function c_rte_lw(device, ncol, nlay, ngpt, top_at_1, nmus, tau, lay_source, lev_inc, lev_dec, sfc_source, &
                       nband, band2gpt, sfc_emis, inc_flux, flux_up, flux_dn, memspace, stream) &
         bind(C, name="ecckd_rte_lw_inc_flux") result(rc)
@@ -62,6 +71,17 @@ module mo_rte_lw
     end function c_rte_lw_byband
   end interface
 contains
+  !> Sets a solver option of the library for the whole process (both solvers; thread-safe).  A host that links a later
+  !> RTE-RRTMGP release than the v1.5 era the defaults follow sets the matching forms once at start-up, e.g.
+  !> `error_msg = rte_set_solver_option("sw_dir_clamp", 1._wp)`.  Empty result = success, as everywhere in RTE.
+  function rte_set_solver_option(name, value) result(error_msg)
+    character(len=*), intent(in) :: name
+    real(wp), intent(in) :: value
+    character(len=128) :: error_msg
+    error_msg = ""
+    if (c_set_solver_option(trim(name) // c_null_char, real(value, c_double)) /= 0) error_msg = c_error_message()
+  end function rte_set_solver_option
+
   function rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, inc_flux, n_gauss_angles, device, &
                   lev_sources_shared) result(error_msg)
     class(ty_optical_props_arry), intent(in) :: optical_props

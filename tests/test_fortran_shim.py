@@ -188,3 +188,49 @@ def test_fortran_fused_lw_fluxes(pkg, gpu, oracle_mod, tmp_path):
                                                            helpers.oracle_gas_items(cols, names), cols["tlev"])
     ofu, ofd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None], 32, 0), sfc, nmus=3)
     assert np.max(np.abs(out["1"][0] - ofu)) < FLUX_ATOL and np.max(np.abs(out["1"][1] - ofd)) < FLUX_ATOL
+
+
+def test_fortran_solver_option_binding_reports_errors(pkg):
+    """mo_rte_lw's rte_set_solver_option (ecckd_set_solver_option behind it) returns the library's message for an
+    unknown name or a value out of range; the driver stops on it like on every other error_msg (no GPU needed)."""
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    for opt, text in (("no_such_option=1", "unknown option"), ("lw_split_seg=11", "10, 12 or 15"), ("novalue", "name=value")):
+        r = subprocess.run([drv, "lw", "a", "b", "c"], capture_output=True, text=True, env=dict(os.environ, ECCKD_SOLVER_OPTION=opt))
+        assert r.returncode != 0 and text in r.stderr.replace("\n ", ""), r.stderr
+
+
+@pytest.mark.gpu
+def test_fortran_solver_option_binding_takes_effect(pkg, gpu, oracle_mod, tmp_path):
+    """Options set from Fortran reach the solvers: an implementation choice (lw_tail_split = 0) leaves the LW fluxes
+    bit-identical, and the SW driver with a version switch (sw_k_floor = 2) agrees with the oracle run with it."""
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    m = oracle_mod.CkdModel(LW_FSCK)
+    ncol = 100
+    cols = synthetic.columns(0, ncol, float(np.exp(m.log_pressure[0])))
+    write_input(tmp_path / "in.bin", cols, synthetic.GAS_ORDER, False)
+    out = []
+    for opt in (None, "lw_tail_split=0"):
+        env = dict(os.environ) if opt is None else dict(os.environ, ECCKD_SOLVER_OPTION=opt)
+        r = subprocess.run([drv, "lw", LW_FSCK, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0", "1"],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        out.append(read_output(tmp_path / "out.bin", ncol, 60))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # version switch: a larger k floor changes the SW fluxes, and the Fortran-set value matches the oracle's
+    ms = oracle_mod.CkdModel(SW_WIDE)
+    cols = synthetic.columns(0, ncol, float(np.exp(ms.log_pressure[0])), shortwave=True)
+    write_input(tmp_path / "insw.bin", cols, synthetic.GAS_ORDER, True)
+    r = subprocess.run([drv, "sw", SW_WIDE, str(tmp_path / "insw.bin"), str(tmp_path / "outsw.bin"), "32"],
+                       capture_output=True, text=True, env=dict(os.environ, ECCKD_SOLVER_OPTION="sw_k_floor=2.0"))
+    assert r.returncode == 0, r.stderr
+    fu, fd = read_output(tmp_path / "outsw.bin", ncol, 60)
+    tau, ssa, g, toa, _ = oracle_mod.gas_optics_ext(ms, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, synthetic.GAS_ORDER))
+    alb = np.repeat(cols["albedo"][None], 27, 0)
+    ofu, ofd, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb, options=oracle_mod.solver_options(sw_k_floor=2.0))
+    dfu, _, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb)
+    assert np.max(np.abs(fu - ofu)) < FLUX_ATOL and np.max(np.abs(fd - ofd)) < FLUX_ATOL
+    assert np.max(np.abs(dfu - ofu)) > 1e-6          # the switch does change the answer
