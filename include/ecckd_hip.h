@@ -373,7 +373,9 @@ int ecckd_get_arithmetic(void);
  *                            second small kernel -- bit-identical fluxes, no idle SIMDs in the last round (1e5 columns:
  *                            3 125 tiles on 1 024 SIMDs).  Needs up to 64 MiB of stream scratch, taken only when it
  *                            can be had without an error (not inside a graph capture that has not seen the call
- *                            before, not beyond a caller-owned buffer): 0 switches it off
+ *                            before, not beyond a caller-owned buffer): 0 switches it off.  A host that hands its own
+ *                            block over (ecckd_set_stream_scratch) and wants the split sizes it
+ *                            max(ecckd_rte_*_scratch_bytes(...), 64 MiB + that)
  *   "sw_tail_split"          the same for rte_sw (persistent grid of three waves per SIMD; one g-point group per wave),
  *                            applied to calls that do not fill one round of waves (< 49 152 columns; it gains nothing
  *                            beyond): 1 (default), 0 off; bit-identical fluxes
