@@ -374,8 +374,9 @@ int ecckd_get_arithmetic(void);
  *                            3 125 tiles on 1 024 SIMDs).  Needs up to 64 MiB of stream scratch, taken only when it
  *                            can be had without an error (not inside a graph capture that has not seen the call
  *                            before, not beyond a caller-owned buffer): 0 switches it off.  A host that hands its own
- *                            block over (ecckd_set_stream_scratch) and wants the split sizes it
- *                            max(ecckd_rte_*_scratch_bytes(...), 64 MiB + that)
+ *                            block over (ecckd_set_stream_scratch) and wants the splits sizes it 64 MiB for rte_lw
+ *                            and ecckd_rte_sw_scratch_bytes(49152, nlay, ngpt) + 64 MiB for rte_sw (the ring of a
+ *                            full grid of waves + the partial sums)
  *   "sw_tail_split"          the same for rte_sw (persistent grid of three waves per SIMD; one g-point group per wave),
  *                            applied to calls that do not fill one round of waves (< 49 152 columns; it gains nothing
  *                            beyond): 1 (default), 0 off; bit-identical fluxes
