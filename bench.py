@@ -264,6 +264,76 @@ def prof_report(L):
     return {names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): (ms[i] / max(cnt[i], 1), int(cnt[i])) for i in range(nk)}
 
 
+def lw_measure(pkg, lw_file, ncol, dtype, steps, warmup, device=0):
+    """One LW gas_optics + rte_lw workload beside the headline (another table and / or precision): value, ms per step,
+    per-kernel HIP-event times, fraction of the HBM roofline at the API-boundary accounting of the precision, and the
+    largest broadband-flux difference of 64 columns against the fp64 CPU oracle."""
+    import torch
+    from rte_ecckd_amd import synthetic
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    L = pkg.lib()
+    k = pkg.GasOpticsEcckd()
+    err = k.load(lw_file, device=device)
+    if err:
+        raise SystemExit(err)
+    ng, nlay = k.get_ngpt(), NLAY
+    press_min = k.get_press_min()
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    case = LwCase(pkg, k, ncol, 0, torch.device("cuda", device), tdt, press_min)
+    for _ in range(max(warmup, 1)):
+        case.step()
+    torch.cuda.synchronize()
+    L.ecckd_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        case.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    L.ecckd_prof_enable(0)
+    kern = prof_report(L)
+    bpc = algorithmic_bytes_per_column(ng)
+    total_b = (bpc["tau"] + bpc["planck"] + bpc["rte_lw"]) * ncol // (2 if dtype == "f32" else 1)
+    m = oracle.CkdModel(lw_file)
+    cols = synthetic.columns(0, 64, press_min)
+    tau, lay, inc, dec, sfc, _ = oracle.gas_optics_int(m, cols["plev"], cols["tlay"], cols["tsfc"], synthetic.gas_items(cols), cols["tlev"])
+    fu, fd = oracle.rte_lw(tau, lay, inc, dec, np.repeat(cols["sfc_emis"][None, :], ng, 0), sfc)
+    dflux = max(float(np.max(np.abs(case.fl.flux_up[:, :64].double().cpu().numpy() - fu))),
+                float(np.max(np.abs(case.fl.flux_dn[:, :64].double().cpu().numpy() - fd))))
+    del case
+    torch.cuda.empty_cache()
+    return {"workload": "synthetic %d columns x %d layers x %d g-points, LW %s, gas_optics + rte_lw (1 angle), %s"
+                        % (ncol, nlay, ng, os.path.basename(lw_file)[36:-3], "fp64" if dtype == "f64" else "fp32"),
+            "value": ncol * nlay * ng / dt / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": dt * 1e3, "dtype": dtype,
+            "kernels_avg_ms": {n: v[0] for n, v in kern.items()},
+            "frac_of_hbm_roofline": total_b / dt / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_cell": total_b / ncol / (nlay * ng),
+            "max_abs_flux_diff_vs_fp64_oracle_Wm2": dflux}
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process group
+    (`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`), pass its output through and
+    return its exit code.  Nothing in this parent touches the GPU (no torch import, no HIP call): the ranks
+    initialise their own devices.  Launched through torch.distributed.run directly (RANK set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:      # rank 0's JSON line (and anything else the ranks print) as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +367,8 @@ def main():
                     help="columns of the side measurement through the Fortran type-bound API in device-resident mode "
                          "(ecckd_driver: host arrays in, fluxes out, tau and sources stay in HBM; 0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args.gpus)
     if args.mode == "sw":
         if args.ncol is None:
             args.ncol = 100000
@@ -592,6 +664,20 @@ def main():
                             "ms_per_step": dt1 * 1e3, "frac_of_hbm_roofline": (total_b / ncol) * n1 / dt1 / 1e9 / HBM_PEAK_GBS}
                 del c1
                 torch.cuda.empty_cache()
+        # BASELINE configs[2] (SW pair, 1e5 columns) and configs[4] (the present higher-g-count LW table, 36 g-points, 1e6
+        # columns, fp64 and fp32 with the flux difference of each against the fp64 oracle) in the same driver-run line
+        out["configs_2"] = None
+        out["configs_4"] = None
+        if side and ncol == 1000000 and args.lut == "fsck" and args.dtype == "f64" and args.arithmetic == "fast":
+            sw = sw_measure(100000, args.steps, args.warmup)
+            out["configs_2"] = {k2: sw[k2] for k2 in ("value", "unit", "ms_per_step", "roofline", "roofline_fp64_valu", "roofline_pipeline",
+                                                      "kernels", "check_max_abs_flux_diff_vs_oracle_Wm2")}
+            out["configs_2"]["workload"] = sw["config"]["workload"]
+            torch.cuda.empty_cache()
+            out["configs_4"] = {dt4: lw_measure(pkg, LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061"), 1000000, dt4, args.steps,
+                                                args.warmup, local_rank) for dt4 in ("f64", "f32")}
+            out["configs_4"]["note"] = ("LW rrtmgp-tol0.061 (36 g-points, 16 bands): the higher-g-count table present in the reference "
+                                        "tree (BASELINE names rrtmgp-tol0.0161, listed in the reference's .MISSING_LARGE_BLOBS)")
         out["host_memspace"] = None
         if args.host_sample > 0 and side and args.dtype == "f64":
             # The reference's calling convention: host arrays in and out (ECCKD_HOST).  Every call stages its
@@ -632,8 +718,14 @@ def main():
 
 
 def main_sw(args):
+    print(json.dumps(sw_measure(args.ncol, args.steps, args.warmup, args.solver_option)), flush=True)
+
+
+def sw_measure(ncol, steps, warmup, solver_option=()):
     """Secondary line: SW wide-tol0.05 (27 g-points), gas_optics (tau, ssa, g) + rte_sw two-stream, fp64,
     single GPU.  Algorithmic bytes: tau, ssa, g written once and read once = 48 B/cell (+ per-column terms)."""
+    import types
+    args = types.SimpleNamespace(ncol=ncol, steps=steps, warmup=warmup, solver_option=list(solver_option))
     import torch
     import rte_ecckd_amd as pkg
     from rte_ecckd_amd import synthetic
@@ -745,7 +837,7 @@ def main_sw(args):
     fu, fd, _ = oracle.rte_sw(tau, ssa, g, cols["mu0"], toa_o, a2, a2)
     dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].cpu().numpy() - fu))),
                 float(np.max(np.abs(fl.flux_dn[:, :64].cpu().numpy() - fd))))
-    print(json.dumps({
+    return ({
         "metric": "Mcol*lay*gpt/s SW gas_optics+rte_sw", "value": cells * args.steps / elapsed / 1e6,
         "unit": "Mcol*lay*gpt/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -754,7 +846,7 @@ def main_sw(args):
         "roofline": roofline, "roofline_fp64_valu": valu_roof,
         "roofline_pipeline": {"bound": "hbm", "achieved": alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "kernels": kernels, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux, "cpu_baseline": None}), flush=True)
+        "kernels": kernels, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux, "cpu_baseline": None})
 
 
 if __name__ == "__main__":

@@ -65,36 +65,66 @@ Arena g_solver_arena[16];
 // Scratch rings of the solvers (rte_sw always; rte_lw beyond 96 layers), stream-ordered: a launch takes the
 // block that belongs to (device, stream).  Work on one stream is ordered, so consecutive calls on a stream
 // reuse its block without any synchronisation, and calls on different streams never share one -- the call
-// stays asynchronous and can be captured in a HIP graph.  A block that has become too small is retired, not
-// freed while a kernel in flight or a captured graph may still hold its address (it is freed at once when the stream
-// has drained and nothing was ever captured) and a larger one is allocated; retired blocks are released by
-// ecckd_release_scratch() or when the process ends.  A caller that wants no
-// allocation inside the library at all hands its own buffer over with ecckd_set_stream_scratch().
+// stays asynchronous and can be captured in a HIP graph.
+// Lifetime rules:
+//  * A call holds a ScratchLease from the moment it asks for a block until it has launched its kernels.  A block that
+//    has become too small is freed at once only when nothing can still refer to it: no other call holds a lease on this
+//    device (another host thread between "got the pointer" and "launched"), the stream has drained, and the block was
+//    never handed to a captured call.  Otherwise it is retired and released by ecckd_release_scratch() or at exit.
+//  * A block handed out while its stream was being captured belongs to that graph from then on: the next eager call on
+//    the stream gets a fresh block (the graph may be replayed on any stream, concurrently with eager calls).
+//  * A caller that wants no allocation inside the library at all hands its own buffer over with
+//    ecckd_set_stream_scratch(); ecckd_release_scratch() leaves such entries alone.
 struct ScratchPool {
   std::mutex mu;
-  struct Block { void *p = nullptr; size_t bytes = 0; bool caller_owned = false; };   // (a block handed to a captured call is never reused: see stream_scratch)
+  struct Block { void *p = nullptr; size_t bytes = 0; bool caller_owned = false; bool captured = false; };
   std::map<hipStream_t, Block> live;
   std::vector<void *> retired;
-  bool any_capture = false;   // a call was captured into a graph with a block of this pool: outgrown blocks are kept
+  int leases = 0;             // calls between acquiring a block and having launched on it
 };
 ScratchPool g_scratch_pool[16];
 
-// Returns the scratch block of (device, stream) with at least `need` bytes in *out.
-int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
+struct ScratchLease {
+  int device = -1;
+  ScratchLease() = default;
+  ScratchLease(const ScratchLease &) = delete;
+  ScratchLease &operator=(const ScratchLease &) = delete;
+  void take(int dev) {   // (pool.mu held by the caller)
+    if (device < 0) { device = dev; ++g_scratch_pool[dev].leases; }
+  }
+  ~ScratchLease() {
+    if (device < 0) return;
+    std::lock_guard<std::mutex> lock(g_scratch_pool[device].mu);
+    --g_scratch_pool[device].leases;
+  }
+};
+
+bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus c = hipStreamCaptureStatusNone;
+  return stream && hipStreamIsCapturing(stream, &c) == hipSuccess && c != hipStreamCaptureStatusNone;
+}
+
+// Returns the scratch block of (device, stream) with at least `need` bytes in *out; `lease` keeps it safe from other
+// host threads until the caller has launched (it must outlive the launches of the call).
+int stream_scratch(int device, hipStream_t stream, size_t need, void **out, ScratchLease &lease) {
   ScratchPool &pool = g_scratch_pool[device];
   std::lock_guard<std::mutex> lock(pool.mu);
+  lease.take(device);
   ScratchPool::Block &b = pool.live[stream];
+  const bool capturing = stream_is_capturing(stream);
+  if (b.captured && !capturing && !b.caller_owned) {   // the block belongs to a captured graph: eager calls move on
+    pool.retired.push_back(b.p);
+    b = ScratchPool::Block{};
+  }
   if (b.bytes >= need) {
-    hipStreamCaptureStatus c0 = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(stream, &c0) == hipSuccess && c0 != hipStreamCaptureStatusNone) pool.any_capture = true;
+    if (capturing && !b.caller_owned) b.captured = true;
     *out = b.p;
     return 0;
   }
   if (b.caller_owned)
     return fail("ecckd: the scratch buffer set with ecckd_set_stream_scratch is too small for this call (" +
-                std::to_string(need) + " bytes needed: ecckd_rte_lw_scratch_bytes / ecckd_rte_sw_scratch_bytes)");
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+                std::to_string(need) + " bytes needed: ecckd_rte_lw_scratch_bytes / ecckd_rte_sw_scratch_bytes, or "
+                "ecckd_rte_lw_tail_scratch_bytes / ecckd_rte_sw_tail_scratch_bytes with the tail splits)");
   if (capturing)
     return fail("ecckd: this call needs " + std::to_string(need) + " bytes of solver scratch on a stream that is being "
                 "captured; run the call once on this stream before the capture, or hand a buffer over with "
@@ -102,36 +132,36 @@ int stream_scratch(int device, hipStream_t stream, size_t need, void **out) {
   void *p = nullptr;
   size_t want = need + need / 4;   // head room: a slightly larger shape on the same stream does not reallocate
   if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();       // the refused request must not surface as the next launch's error
     want = need;
     HIPCHK(hipMalloc(&p, want));
   }
-  if (b.p) {
-    // The outgrown block: free it now if nothing can still refer to it -- the stream has drained and no graph was
-    // captured on this device (a captured graph holds scratch addresses for as long as it lives); else retire it.
-    if (!pool.any_capture && hipStreamQuery(stream) == hipSuccess) (void)hipFree(b.p);
+  if (b.p) {   // the outgrown block: see the lifetime rules above
+    if (!b.captured && pool.leases == 1 && hipStreamQuery(stream) == hipSuccess) (void)hipFree(b.p);
     else pool.retired.push_back(b.p);
+    (void)hipGetLastError();       // hipStreamQuery's hipErrorNotReady is not an error of this call
   }
-  b.p = p; b.bytes = want; b.caller_owned = false;
+  b.p = p; b.bytes = want; b.caller_owned = false; b.captured = false;
   *out = p;
   return 0;
 }
 
 // Same block, for a use the call can do without (the tail split of rte_lw): nullptr instead of an error when the block
 // cannot be provided (caller-owned block too small, stream being captured, allocation refused).
-void *stream_scratch_optional(int device, hipStream_t stream, size_t need) {
+void *stream_scratch_optional(int device, hipStream_t stream, size_t need, ScratchLease &lease) {
   {
     ScratchPool &pool = g_scratch_pool[device];
     std::lock_guard<std::mutex> lock(pool.mu);
     const auto it = pool.live.find(stream);
+    const bool capturing = stream_is_capturing(stream);
     const bool have = it != pool.live.end() && it->second.bytes >= need;
     if (!have) {
       if (it != pool.live.end() && it->second.caller_owned) return nullptr;
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
+      if (capturing) return nullptr;
     }
   }
   void *p = nullptr;
-  if (stream_scratch(device, stream, need, &p)) {
+  if (stream_scratch(device, stream, need, &p, lease)) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -158,7 +188,10 @@ thread_local int g_f32 = 0;
 thread_local int g_shared_levels = 0;
 thread_local const double *g_inc_flux = nullptr;   // set by ecckd_rte_lw_inc_flux around ecckd_rte_lw
 // set by the *_byband entry points around the per-band solver calls: band of every g-point of the sub-range
-thread_local int g_band_override = -1;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
+thread_local int g_band_override = -1;
+// set by ecckd_sw_fluxes around ecckd_rte_sw: the solver derives ssa / g / toa itself (RteSwArgs::derive)
+struct SwDerive { const double *plev, *rayleigh, *solar; double gw; };
+thread_local const SwDerive *g_sw_derive = nullptr;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
 struct PlanRecord {
   const int *is_scalar = nullptr;   // per gas of the list: its mole fraction would be passed as one number
@@ -194,6 +227,7 @@ struct SolverOptions {
   std::atomic<int> gas_merge_scalars{1};
   std::atomic<int> lw_tail_split{1};
   std::atomic<int> sw_tail_split{1};
+  std::atomic<int> sw_solver{0};   // 0 layer-systolic (kernels_rte_sw_sys.hip; up to 60 layers), 1 per-lane two-pass kernel
 };
 SolverOptions g_opt;
 
@@ -527,8 +561,13 @@ int ecckd_set_solver_option(const char *name, double value) {
   } else if (n == "gas_merge_scalars") g_opt.gas_merge_scalars.store(value != 0. ? 1 : 0);
   else if (n == "lw_tail_split") g_opt.lw_tail_split.store(value != 0. ? 1 : 0);
   else if (n == "sw_tail_split") g_opt.sw_tail_split.store(value != 0. ? 1 : 0);
+  else if (n == "sw_solver") {
+    if (value != 0. && value != 1.) return fail("ecckd_set_solver_option: sw_solver must be 0 (layer-systolic) or 1 (two-pass per lane)");
+    g_opt.sw_solver.store((int)value);
+  }
   else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
-                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split, sw_tail_split)");
+                   "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split, "
+                   "sw_tail_split, sw_solver)");
   return 0;
 }
 
@@ -545,6 +584,7 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "gas_merge_scalars") *value = g_opt.gas_merge_scalars.load();
   else if (n == "lw_tail_split") *value = g_opt.lw_tail_split.load();
   else if (n == "sw_tail_split") *value = g_opt.sw_tail_split.load();
+  else if (n == "sw_solver") *value = g_opt.sw_solver.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -573,11 +613,15 @@ int ecckd_release_scratch(int device) {
   std::lock_guard<std::mutex> lock(pool.mu);
   if (pool.live.empty() && pool.retired.empty()) return 0;
   HIPCHK(hipSetDevice(device));
+  if (pool.leases > 0) return fail("ecckd_release_scratch: another thread is inside a solver call on this device");
   HIPCHK(hipDeviceSynchronize());   // nothing in flight may still use a block
-  for (auto &kv : pool.live)
-    if (kv.second.p && !kv.second.caller_owned) (void)hipFree(kv.second.p);
+  // (graphs captured with library-owned scratch hold these addresses: destroy them before releasing -- see the header)
+  for (auto it = pool.live.begin(); it != pool.live.end();) {
+    if (it->second.caller_owned) { ++it; continue; }   // the caller's buffer stays registered
+    if (it->second.p) (void)hipFree(it->second.p);
+    it = pool.live.erase(it);
+  }
   for (void *p : pool.retired) (void)hipFree(p);
-  pool.live.clear();
   pool.retired.clear();
   return 0;
 }
@@ -1117,15 +1161,16 @@ int ecckd_rte_lw(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_g
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const size_t scratch = ecckd::rte_lw_scratch_bytes(ncol, nlay, ngpt);
   const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
+  ScratchLease lease;   // (held until the kernels of this call have been launched)
   if (scratch) {   // more than 96 layers: stream-ordered scratch ring, no synchronisation (see ScratchPool)
     void *sp = nullptr;
-    if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
+    if (stream_scratch(device, launch_stream, scratch, &sp, lease)) return 1;
     a.scratch = static_cast<double *>(sp);
   } else if (g_opt.lw_tail_split.load()) {   // tail tiles one g-pair per wave (rte_lw_tail_plan); optional, same bits
     long first = -1;
     const size_t need = ecckd::rte_lw_tail_plan(a, simd_slots(device), &first);
     if (need) {
-      if (void *sp = stream_scratch_optional(device, launch_stream, need)) {
+      if (void *sp = stream_scratch_optional(device, launch_stream, need, lease)) {
         a.partials = static_cast<double *>(sp);
         a.tail_first = first;
       }
@@ -1221,7 +1266,7 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
                  int memspace, void *stream) {
   if (check_dims(ncol, nlay)) return 1;
-  if (!tau || !ssa || !g || !mu0 || !toa_flux || !sfc_alb_dir || !sfc_alb_dif || !flux_up || !flux_dn)
+  if (!tau || !mu0 || !sfc_alb_dir || !sfc_alb_dif || !flux_up || !flux_dn || (!g_sw_derive && (!ssa || !g || !toa_flux)))
     return fail("ecckd_rte_sw: null argument");
   ecckd::RteSwArgs a{};
   if (g_band_override >= 0) std::memset(a.gpt2band, g_band_override, sizeof a.gpt2band);
@@ -1232,15 +1277,35 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   a.exact_division = g_arith.load() != 0;
   a.k_floor = g_opt.sw_k_floor.load();
   a.dir_clamp = g_opt.sw_dir_clamp.load();
+  a.f32 = g_f32;
+  if (g_sw_derive) {   // ecckd_sw_fluxes: ssa / g / toa derived inside the solver (RteSwArgs::derive)
+    a.derive = 1;
+    a.plev = g_sw_derive->plev; a.rayleigh = g_sw_derive->rayleigh; a.solar = g_sw_derive->solar; a.gw = g_sw_derive->gw;
+  }
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
-  const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
   const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
+  ScratchLease lease;   // (held until the kernels of this call have been launched)
+  const int cus = simd_slots(device) / 4;
+  a.use_sys = g_opt.sw_solver.load() == 0 && ecckd::rte_sw_sys_applies(a) && cus > 0;
+  if ((a.f32 || a.derive) && !a.use_sys)
+    return fail("ecckd_rte_sw: single precision and the fused shortwave path need the layer-systolic solver (sw_solver = 0, at most 60 layers)");
+  if (a.use_sys) {
+    // layer-systolic solver: no scratch ring; the g-point chunks of the last part-empty round go through partial sums
+    if (g_opt.sw_tail_split.load()) {
+      const size_t need = ecckd::rte_sw_sys_plan(a, cus);
+      if (need) {
+        if (void *sp = stream_scratch_optional(device, launch_stream, need, lease)) a.partials = static_cast<double *>(sp);
+        else { a.sys_tail_first = -1; a.sys_gchunk = 0; }
+      }
+    }
+  } else {
+  const size_t scratch = ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt);
   if (g_opt.sw_tail_split.load()) {   // tail tiles one g-point group per wave (rte_sw_tail_plan); optional, same bits
     long first = -1;
     size_t partials_at = 0;
     const size_t need = ecckd::rte_sw_tail_plan(a, &first, &partials_at);
     if (need) {
-      if (void *sp = stream_scratch_optional(device, launch_stream, need > scratch ? need : scratch)) {
+      if (void *sp = stream_scratch_optional(device, launch_stream, need > scratch ? need : scratch, lease)) {
         a.scratch = static_cast<double *>(sp);
         a.partials = reinterpret_cast<double *>(static_cast<char *>(sp) + partials_at);
         a.tail_first = first;
@@ -1249,16 +1314,18 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   }
   if (scratch && a.tail_first < 0) {   // stream-ordered scratch ring, no synchronisation (see ScratchPool)
     void *sp = nullptr;
-    if (stream_scratch(device, launch_stream, scratch, &sp)) return 1;
+    if (stream_scratch(device, launch_stream, scratch, &sp, lease)) return 1;
     a.scratch = static_cast<double *>(sp);
   }
+  }
+  auto launch = [&](hipStream_t st) { return a.use_sys ? ecckd::launch_rte_sw_sys(a, cus, st) : ecckd::launch_rte_sw(a, st); };
   if (memspace == ECCKD_DEVICE) {
     a.tau = tau; a.ssa = ssa; a.g = g; a.mu0 = mu0; a.toa = toa_flux;
     a.alb_dir = sfc_alb_dir; a.alb_dif = sfc_alb_dif;
     a.flux_up = flux_up; a.flux_dn = flux_dn; a.flux_dir = flux_dir;
     {
       ProfScope prof("rte_sw", launch_stream);
-      HIPCHK(ecckd::launch_rte_sw(a, launch_stream));
+      HIPCHK(launch(launch_stream));
     }
     return 0;
   }
@@ -1287,7 +1354,7 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
     return 1;
   a.mu0 = d_mu0; a.toa = d_toa; a.alb_dir = d_ad; a.alb_dif = d_af;
   a.flux_up = d_up; a.flux_dn = d_dn; a.flux_dir = flux_dir ? d_dir : nullptr;
-  HIPCHK(ecckd::launch_rte_sw(a, s));
+  HIPCHK(launch(s));
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   if (flux_dir && d2h(flux_dir, d_dir, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
@@ -1502,8 +1569,9 @@ int ecckd_rte_lw_fused(const ecckd_model_t *m, int ncol, int nlay, int top_at_1,
   if (ncol == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   void *sp = nullptr;
+  ScratchLease lease;
   const size_t extra = fused_scratch_doubles(m, ncol, nlay);
-  if (extra && stream_scratch(m->device, st, extra * sizeof(double), &sp)) return 1;
+  if (extra && stream_scratch(m->device, st, extra * sizeof(double), &sp, lease)) return 1;
   return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,
                           flux_dn, static_cast<double *>(sp), st);
 }
@@ -1526,8 +1594,9 @@ int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *pl
   if (memspace == ECCKD_DEVICE) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     void *tau_p = nullptr;   // tau lives in the stream's scratch block between the two kernels
+    ScratchLease lease;
     const size_t extra = fused_scratch_doubles(m, ncol, nlay);
-    if (stream_scratch(m->device, st, (n3 + 32 + extra) * sizeof(double), &tau_p)) return 1;
+    if (stream_scratch(m->device, st, (n3 + 32 + extra) * sizeof(double), &tau_p, lease)) return 1;
     double *d_tau = static_cast<double *>(tau_p);
     if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, d_tau, false, nullptr, nullptr, nullptr, nullptr, st)) return 1;
     return rte_lw_fused_dev(m, ncol, nlay, top_at_1, n_gauss_angles, d_tau, tlay, tlev, tsfc, sfc_emis, inc_flux, flux_up,

@@ -136,6 +136,21 @@ struct RteSwArgs {
   // tail split (rte_sw_tail_plan): tiles from tail_first on are solved one g-point group per wave; -1: none
   long tail_first = -1;
   double *partials = nullptr;  // [tail tile][group][up, dn, dir][nlay+1][columns per tile]
+  int f32 = 0;                 // 1: the data pointers address float arrays (layer-systolic solver only)
+  // Layer-systolic solver (kernels_rte_sw_sys.hip; rte_sw_sys_applies()): tiles of 64 columns; tiles from sys_tail_first
+  // on are solved in chunks of sys_gchunk g-points per block, the chunk sums go through `partials`
+  // ([tail tile][chunk][up, dn, dir][nlay+1][64]) and are added in chunk order by rte_sw_tail_reduce.
+  int use_sys = 0;
+  long sys_tail_first = -1;
+  int sys_gchunk = 0;
+  int sys_npark = 0;           // (set by the launcher) lower waves that park the next g-point's coefficients in LDS
+  unsigned sys_park_at = 0;    // (set by the launcher) byte offset of the parking areas in the block's LDS
+  // Fused shortwave path (ecckd_sw_fluxes): `tau` is the total optical depth and nothing else is read per cell --
+  // ssa = (moles*rayleigh(g))/tau with moles = (plev(l+1)-plev(l))*gw, g = 0, toa = solar(g): gas_optics_ext's own
+  // expressions (src/gas_optics_ecckd.f90:313-317,455-472).  derive != 0 selects it; ssa / g / toa are then unused.
+  int derive = 0;
+  const double *plev = nullptr, *rayleigh = nullptr, *solar = nullptr;   // plev(ncol,nlay+1) device; (ng) device tables
+  double gw = 0.;
 };
 
 // Spectral-output solvers (kernels_rte_gpt.hip): RTE-RRTMGP's kernel-level interfaces.  LW uses tau, lay_source,
@@ -195,5 +210,11 @@ hipError_t launch_rte_lw_split(const RteLwArgs &a, hipStream_t s);
 hipError_t launch_rte_lw_planck(const RteLwArgs &a, const double *planck, int ntp, double t0, double dt, const double *tlay,
                                 const double *tlev, const double *tsfc, hipStream_t s);
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s);
+// layer-systolic shortwave solver (kernels_rte_sw_sys.hip): any precision, nlay <= 60
+bool rte_sw_sys_applies(const RteSwArgs &a);
+size_t rte_sw_sys_plan(RteSwArgs &a, int cus);   // fills sys_tail_first / sys_gchunk; returns the bytes of `partials` (0: none)
+hipError_t launch_rte_sw_sys(const RteSwArgs &a, int cus, hipStream_t s);
+// partial sums of the tail tiles -> fluxes, in chunk order (kernels_rte_sw.hip)
+hipError_t launch_rte_sw_tail_reduce(const RteSwArgs &a, int nchunks, int cw, long tail_first, long ntail, hipStream_t s);
 
 }  // namespace ecckd

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "sw_two_stream.hpp"
 
 namespace ecckd {
 namespace {
@@ -64,60 +65,6 @@ constexpr int kSwWaves = ECCKD_SW_WAVES;
 // order-independent result (see kernels_rte_lw.hip).
 __device__ __forceinline__ void acc_add(double *p, double v, bool owner) {
   __hip_atomic_fetch_add(p, owner ? v : 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// sw_two_stream for one cell: Zdunkowski PIFM coefficients, diffuse and direct reflectance and
-// transmittance, direct-beam transmittance.
-struct TwoStream { double Rdif, Tdif, Rdir, Tdir, Tnoscat; };
-// 1/x: the IEEE division sequence (~15 instructions) in the reference-order arithmetic mode; in the fast
-// mode v_rcp_f64 and two Newton steps (~1 ulp, 6 instructions).  The solver is bound by fp64 issue:
-// -8.5 % on the kernel, fluxes unchanged to 1e-11 W m-2.
-template <bool FAST>
-__device__ __forceinline__ double rcp(double x) {
-  if (!FAST) return 1. / x;
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.), r, r);
-  r = fma(fma(-x, r, 1.), r, r);
-  return r;
-}
-// G0: the asymmetry parameter of the whole wave is zero -- what ecCKD's gas optics writes (g = 0, src/gas_optics_ecckd.f90:460);
-// the kernel checks it per layer with a wave vote on the values it has loaded anyway.  With gq a literal 0 the compiler
-// folds (1 - g), 3*mu0*g and the duplicated alpha / k*gamma terms: 12 of ~130 fp64 operations less per cell and pass,
-// every folded operation exact (x*1, x+0), so the same bits as the general form.  Measured -6.7 % on the kernel.
-template <bool FAST, bool CLAMP, bool G0>
-__device__ __forceinline__ TwoStream two_stream(double tau, double w0, double gq_in, double mu0, double mu0_inv, double k_floor) {
-  const double gq = G0 ? 0. : gq_in;
-  const double eps = 2.220446049250313e-16;   // epsilon(1._wp)
-  const double gamma1 = (8. - w0 * (5. + 3. * gq)) * .25;
-  const double gamma2 = 3. * (w0 * (1. - gq)) * .25;
-  const double gamma3 = (2. - 3. * mu0 * gq) * .25;
-  const double gamma4 = 1. - gamma3;
-  const double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
-  const double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-  const double kk0 = (gamma1 - gamma2) * (gamma1 + gamma2);
-  const double k = sqrt(kk0 > k_floor ? kk0 : k_floor);   // k_floor = 1e-12 unless ecckd_set_solver_option moved it
-  const double exp_minusktau = exp(-tau * k);
-  const double exp_minus2ktau = exp_minusktau * exp_minusktau;
-  double RT_term = rcp<FAST>(k * (1. + exp_minus2ktau) + gamma1 * (1. - exp_minus2ktau));
-  TwoStream r;
-  r.Rdif = RT_term * gamma2 * (1. - exp_minus2ktau);
-  r.Tdif = RT_term * 2. * k * exp_minusktau;
-  r.Tnoscat = exp(-tau * mu0_inv);
-  const double k_mu = k * mu0, k_gamma3 = k * gamma3, k_gamma4 = k * gamma4;
-  const double d = 1. - k_mu * k_mu;
-  if (FAST) RT_term = w0 * RT_term * rcp<true>(fabs(d) >= eps ? d : eps);
-  else RT_term = w0 * RT_term / (fabs(d) >= eps ? d : eps);
-  r.Rdir = RT_term * ((1. - k_mu) * (alpha2 + k_gamma3) - (1. + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
-                      2.0 * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * r.Tnoscat);
-  r.Tdir = -RT_term * ((1. + k_mu) * (alpha1 + k_gamma4) * r.Tnoscat -
-                       (1. - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * r.Tnoscat -
-                       2.0 * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
-  if (CLAMP) {   // later RTE-RRTMGP releases: the direct beam can neither gain energy nor go negative
-    const double lim = 1. - r.Tnoscat;
-    r.Rdir = fmax(0., fmin(r.Rdir, lim));
-    r.Tdir = fmax(0., fmin(r.Tdir, lim - r.Rdir));
-  }
-  return r;
 }
 
 // RECOMPUTE = true: pass 2 reads tau/ssa/g again and recomputes the two-stream coefficients; only the
@@ -202,8 +149,8 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
           const long q = base + (long)ncol * (lay0 + lstep * (s - kPF > 0 ? s - kPF : 0));
           ptau[d] = a.tau[q]; pssa[d] = a.ssa[q]; pg[d] = a.g[q];
         }
-        const TwoStream ts = __all(cg == 0.) ? two_stream<FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
-                                             : two_stream<FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
+        const TwoStream ts = __all(cg == 0.) ? two_stream<double, FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
+                                             : two_stream<double, FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
         const double denom = rcp<FAST>(1. - ts.Rdif * albedo);                             // adding, Eq 10
         if (!RECOMPUTE) {
           sA[64L * s] = ts.Tdif * denom;
@@ -260,8 +207,8 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
         }
         double A, B, C, Tn;
         if (RECOMPUTE) {
-          const TwoStream ts = __all(cg == 0.) ? two_stream<FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
-                                               : two_stream<FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
+          const TwoStream ts = __all(cg == 0.) ? two_stream<double, FAST, CLAMP, true>(ctau, cssa, cg, mu0, mu0_inv, k_floor)
+                                               : two_stream<double, FAST, CLAMP, false>(ctau, cssa, cg, mu0, mu0_inv, k_floor);
           const double denom = rcp<FAST>(1. - ts.Rdif * alb_next);     // the same expression as in pass 1: same bits
           A = ts.Tdif * denom; B = ts.Rdif * denom; C = ts.Tdir * denom; Tn = ts.Tnoscat;
         } else {
@@ -307,9 +254,10 @@ __global__ void __launch_bounds__(64, ECCKD_SW_WAVES_PER_SIMD) rte_sw_kernel(con
 
 // Sums the per-group partial fluxes of the tail tiles in group order: the order in which a whole-tile wave adds the
 // same values to accumulators that start at +0, hence the same bits (see rte_lw_tail_reduce, kernels_rte_lw.hip).
+template <typename real>
 __global__ void __launch_bounds__(256) rte_sw_tail_reduce(const double *partials, int ngroups, int nlev, int cw, long tail_first,
-                                                          long ntail, int ncol, long lev0, long lstep, double *flux_up,
-                                                          double *flux_dn, double *flux_dir) {
+                                                          long ntail, int ncol, long lev0, long lstep, real *flux_up,
+                                                          real *flux_dn, real *flux_dir) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= ntail * nlev * cw) return;
   const int cl = (int)(idx % cw), s = (int)((idx / cw) % nlev);
@@ -324,9 +272,9 @@ __global__ void __launch_bounds__(256) rte_sw_tail_reduce(const double *partials
     dir += p[2L * nlev * cw];
   }
   const long q = col + (long)ncol * (lev0 + lstep * s);
-  flux_up[q] = up;
-  flux_dn[q] = dn;
-  if (flux_dir) flux_dir[q] = dir;
+  flux_up[q] = (real)up;
+  flux_dn[q] = (real)dn;
+  if (flux_dir) flux_dir[q] = (real)dir;
 }
 
 __global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *toa) {
@@ -390,6 +338,7 @@ size_t rte_sw_tail_plan(const RteSwArgs &a, long *tail_first, size_t *partials_a
 
 hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   if (a.ncol <= 0) return hipSuccess;
+  if (a.f32 || a.derive) return hipErrorInvalidValue;   // single precision / fused form: layer-systolic solver only
   constexpr int CW = ECCKD_SW_CW;
   auto k = a.dir_clamp ? (a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false, true> : rte_sw_kernel<CW, kSwRecompute, true, true>)
                        : (a.exact_division ? rte_sw_kernel<CW, kSwRecompute, false, false> : rte_sw_kernel<CW, kSwRecompute, true, false>);
@@ -406,11 +355,21 @@ hipError_t launch_rte_sw(const RteSwArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, s, a);
   e = hipGetLastError();
   if (e != hipSuccess || ntail == 0) return e;
+  return launch_rte_sw_tail_reduce(a, ngroups, CW, a.tail_first, ntail, s);
+}
+
+hipError_t launch_rte_sw_tail_reduce(const RteSwArgs &a, int nchunks, int cw, long tail_first, long ntail, hipStream_t s) {
   const int nlev = a.nlay + 1;
-  const long n = ntail * nlev * CW;
+  const long n = ntail * nlev * cw;
+  if (n <= 0) return hipSuccess;
   const long lev0 = a.top_at_1 ? 0 : a.nlay, lstep = a.top_at_1 ? 1 : -1;
-  hipLaunchKernelGGL(rte_sw_tail_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partials, ngroups, nlev, CW,
-                     a.tail_first, ntail, a.ncol, lev0, lstep, a.flux_up, a.flux_dn, a.flux_dir);
+  if (a.f32)
+    hipLaunchKernelGGL(rte_sw_tail_reduce<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partials, nchunks, nlev, cw,
+                       tail_first, ntail, a.ncol, lev0, lstep, reinterpret_cast<float *>(a.flux_up),
+                       reinterpret_cast<float *>(a.flux_dn), reinterpret_cast<float *>(a.flux_dir));
+  else
+    hipLaunchKernelGGL(rte_sw_tail_reduce<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partials, nchunks, nlev, cw,
+                       tail_first, ntail, a.ncol, lev0, lstep, a.flux_up, a.flux_dn, a.flux_dir);
   return hipGetLastError();
 }
 

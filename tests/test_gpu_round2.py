@@ -267,9 +267,19 @@ def _sw_case(pkg, gpu, rng, ncol, nlay=60, ng=9):
 
 
 def test_rte_sw_and_deep_rte_lw_in_hip_graphs(pkg, gpu):
-    """rte_sw (always uses a scratch ring) and rte_lw with 137 layers (scratch ring beyond 96 layers) captured in
+    """rte_sw with the two-pass kernel (sw_solver = 1: always uses a scratch ring; the layer-systolic default needs none,
+    tests/test_gpu_round3.py) and rte_lw with 137 layers (scratch ring beyond 96 layers) captured in
     HIP graphs after one warm-up call on the capturing stream; a capture that would have to allocate fails with
     a message instead of invalidating the capture silently; a caller-owned scratch buffer needs no warm-up."""
+    import torch
+    pkg.set_solver_option("sw_solver", 1)
+    try:
+        _graphs_body(pkg, gpu)
+    finally:
+        pkg.set_solver_option("sw_solver", 0)
+
+
+def _graphs_body(pkg, gpu):
     import torch
     rng = np.random.default_rng(8)
     ncol = 512
@@ -1042,9 +1052,11 @@ def test_rte_lw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, nmus, top_
     (1003, 37, 14, False, 1),     # other layer count, bottom-up arrays, partly empty last tile and last g-point group
 ])
 def test_rte_sw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, top_at_1, clamp):
-    """rte_sw with the tail split ("sw_tail_split", default) against whole-tile waves: the same bits in flux_up,
-    flux_dn and flux_dn_dir, in both arithmetic modes."""
+    """rte_sw, two-pass kernel (sw_solver = 1), with the tail split ("sw_tail_split", default) against whole-tile waves: the
+    same bits in flux_up, flux_dn and flux_dn_dir, in both arithmetic modes.  (The layer-systolic default sums the
+    g-points of SMALL calls in chunks, which is not bit-neutral: tests/test_gpu_round3.py.)"""
     import torch
+    pkg.set_solver_option("sw_solver", 1)
     rng = np.random.default_rng(ncol)
     tau = rng.uniform(0.001, 2.0, (ng, nlay, ncol)); ssa = rng.uniform(0.0, 0.999, (ng, nlay, ncol))
     g = rng.uniform(0.0, 0.8, (ng, nlay, ncol)) * (rng.uniform(size=(1, 1, ncol)) < 0.5)
@@ -1072,3 +1084,4 @@ def test_rte_sw_tail_split_is_bit_identical(pkg, gpu, ncol, nlay, ng, top_at_1, 
         pkg.set_arithmetic(0)
         pkg.set_solver_option("sw_tail_split", 1)
         pkg.set_solver_option("sw_dir_clamp", 0)
+        pkg.set_solver_option("sw_solver", 0)

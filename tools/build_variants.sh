@@ -15,7 +15,7 @@ for v in "$@"; do
     d=/tmp/ecckd_var/v$i; rm -rf $d; mkdir -p $d
     tf="$v"; of=""
     case "$v" in ALL:*) of="${v#ALL:}"; tf="${v#ALL:}";; esac
-    for s in kernels_gas_fused.hip kernels_tau.hip kernels_rte_lw.hip kernels_rte_lw_split.hip kernels_rte_sw.hip; do /opt/rocm/bin/hipcc $BASE $tf -c $s -o $d/${s%.*}.o & done
+    for s in kernels_gas_fused.hip kernels_tau.hip kernels_rte_lw.hip kernels_rte_lw_split.hip kernels_rte_sw.hip kernels_rte_sw_sys.hip; do /opt/rocm/bin/hipcc $BASE $tf -c $s -o $d/${s%.*}.o & done
     for s in kernels_planck.hip kernels_rte_gpt.hip capi.cpp nc_capi.cpp model.cpp cdf1.cpp; do
       /opt/rocm/bin/hipcc $BASE $of -c $s -o $d/${s%.*}.o
     done
