@@ -278,6 +278,51 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
                  const double *sfc_alb_dif, double *flux_up, double *flux_dn, double *flux_dir,
                  int memspace, void *stream);
 
+/* Single-precision flavours of the shortwave pair and of ecckd_rte_lw_inc_flux (a host built with RTE-RRTMGP's
+ * RTE_USE_SP: wp = real32, src/gas_optics_ecckd.f90:6).  Every data array is float, arithmetic is float, the g-point
+ * sums are accumulated in double and rounded once.  ecckd_gas_optics_sw_f32: one-pass gas lists (all ecCKD files);
+ * ecckd_rte_sw_f32: the layer-systolic solver (at most 60 layers). */
+int ecckd_gas_optics_sw_f32(const ecckd_model_t *model, int ncol, int nlay, const float *plev, const float *tlay,
+                            int ngas, const char *gas_names, const float *const *vmr,
+                            const long long *vmr_col_stride, const long long *vmr_lay_stride,
+                            const double *vmr_scalar, float *tau, float *ssa, float *g, float *toa_src,
+                            int memspace, void *stream);
+int ecckd_rte_sw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, const float *tau, const float *ssa,
+                     const float *g, const float *mu0, const float *toa_flux, int nband, const int *band2gpt,
+                     const float *sfc_alb_dir, const float *sfc_alb_dif, float *flux_up, float *flux_dn,
+                     float *flux_dir, int memspace, void *stream);
+int ecckd_rte_lw_inc_flux_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
+                              const float *tau, const float *lay_source, const float *lev_source_inc,
+                              const float *lev_source_dec, const float *sfc_source, int nband,
+                              const int *band2gpt, const float *sfc_emis, const float *inc_flux, float *flux_up,
+                              float *flux_dn, int memspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused shortwave path (SURVEY.md section 8(f) rank 4 for the shortwave; no counterpart call in the reference, whose
+ * block loop calls gas_optics and rte_sw back to back: ecckd_rfmip_sw.F90:118-154).  gas_optics_ext derives ssa, g and
+ * toa_src from plev and two small tables (src/gas_optics_ecckd.f90:455-472: ssa = tau_rayleigh/tau with
+ * tau_rayleigh = (plev(l+1)-plev(l))*global_weight*rayleigh_molar_scattering_coeff(g) (:313-317), g = 0,
+ * toa_src = solar_irradiance(g)), so a host that only needs fluxes moves the TOTAL optical depth alone: gas optics
+ * writes tau (8 B/cell) and the solver evaluates those same expressions while it reads it (8 B/cell) -- 16 instead of
+ * 48 B per (column, layer, g-point).  Same arithmetic per cell: fluxes bit-identical to ecckd_gas_optics_sw +
+ * ecckd_rte_sw.  tau lives in library-owned stream-ordered scratch.  Fast arithmetic mode, layer-systolic solver
+ * (at most 60 layers); ECCKD_DEVICE or ECCKD_HOST.
+ *   toa_scale(ncol) or NULL: toa(i,g) = solar_irradiance(g)*toa_scale(i) -- the drivers' rescaling to the file's total
+ *   solar irradiance (ecckd_rfmip_sw.F90:126-133); mu0(ncol), sfc_alb_dir/dif(nband,ncol) as ecckd_rte_sw;
+ *   flux_dir may be NULL.
+ * bench.py reports it apart from the API-boundary roofline ("fused_sw").
+ * --------------------------------------------------------------------------------------- */
+int ecckd_sw_fluxes(const ecckd_model_t *model, int ncol, int nlay, const double *plev, const double *tlay, int ngas,
+                    const char *gas_names, const double *const *vmr, const long long *vmr_col_stride,
+                    const long long *vmr_lay_stride, const double *vmr_scalar, int top_at_1, const double *mu0,
+                    const double *toa_scale, const double *sfc_alb_dir, const double *sfc_alb_dif, double *flux_up,
+                    double *flux_dn, double *flux_dir, int memspace, void *stream);
+int ecckd_sw_fluxes_f32(const ecckd_model_t *model, int ncol, int nlay, const float *plev, const float *tlay, int ngas,
+                        const char *gas_names, const float *const *vmr, const long long *vmr_col_stride,
+                        const long long *vmr_lay_stride, const double *vmr_scalar, int top_at_1, const float *mu0,
+                        const float *toa_scale, const float *sfc_alb_dir, const float *sfc_alb_dif, float *flux_up,
+                        float *flux_dn, float *flux_dir, int memspace, void *stream);
+
 /* Spectral (per-band) fluxes: what RTE-RRTMGP callers get by passing a ty_fluxes_byband to rte_lw /
  * rte_sw instead of the ty_fluxes_broadband the reference drivers use (ecckd_rfmip_lw.F90:108-109).
  * bnd_flux_*(ncol,nlay+1,nband) = sum over the g-points of each band (one solver pass per band over its
@@ -374,12 +419,17 @@ int ecckd_get_arithmetic(void);
  *                            3 125 tiles on 1 024 SIMDs).  Needs up to 64 MiB of stream scratch, taken only when it
  *                            can be had without an error (not inside a graph capture that has not seen the call
  *                            before, not beyond a caller-owned buffer): 0 switches it off.  A host that hands its own
- *                            block over (ecckd_set_stream_scratch) and wants the splits sizes it 64 MiB for rte_lw
- *                            and ecckd_rte_sw_scratch_bytes(49152, nlay, ngpt) + 64 MiB for rte_sw (the ring of a
- *                            full grid of waves + the partial sums)
- *   "sw_tail_split"          the same for rte_sw (persistent grid of three waves per SIMD; one g-point group per wave),
- *                            applied to calls that do not fill one round of waves (< 49 152 columns; it gains nothing
- *                            beyond): 1 (default), 0 off; bit-identical fluxes
+ *                            block over (ecckd_set_stream_scratch) sizes it with ecckd_rte_lw_tail_scratch_bytes /
+ *                            ecckd_rte_sw_tail_scratch_bytes (+ ecckd_rte_*_scratch_bytes where that is not 0)
+ *   "sw_tail_split"          the same for rte_sw: 1 (default), 0 off; bit-identical fluxes.  Layer-systolic solver: the
+ *                            tiles beyond the last full round of blocks (one block per CU; every tile of a call of
+ *                            less than 16 384 columns) one g-point per block, up to 128 MiB of partial sums.  Two-pass
+ *                            solver: calls that do not fill one round of its persistent grid, one g-point group per wave
+ *   "sw_solver"              0 (default): layer-systolic solver (kernels_rte_sw_sys.hip: the two-stream coefficients are
+ *                            computed once and stay in registers between the sweeps, the layers of a column are spread
+ *                            over the waves of a block; at most 60 layers, no scratch ring); 1: two-pass kernel (any
+ *                            layer count; reads tau / ssa / g twice, scratch ring).  The same arithmetic per (column,
+ *                            g-point); the g-point sums are ordered differently (sequential / shuffle tree)
  *   "gas_merge_scalars"      fast arithmetic mode, fp64: 1 (default) the gases of gas_desc given as ONE number for the call
  *                            (vmr pointer NULL + vmr_scalar; get_vmr broadcasts them, src/gas_optics_ecckd.f90:351) and
  *                            the none_ composite share one table sum_k m_k*coefficient_k, m_k = vmr | vmr - reference | 1,
@@ -398,10 +448,17 @@ int ecckd_get_solver_option(const char *name, double *value);
  * synchronisation; inside a stream capture nothing is allocated (a call that would have to fails with a
  * message).  ecckd_set_stream_scratch hands a caller-owned device buffer over for the calls on `stream`
  * (buffer == NULL, bytes == 0 takes it back); ecckd_*_scratch_bytes say how much a shape needs (0: none);
- * ecckd_release_scratch synchronises the device and frees every library-owned block.
+ * ecckd_release_scratch synchronises the device and frees every library-owned block (caller-owned buffers stay
+ * registered).  A block that was handed to a captured call belongs to that graph: the next eager call on the stream
+ * takes a fresh one, so a graph may be replayed on any stream; graphs captured back to back on one stream share a
+ * block (replay those on one stream), and a graph must be destroyed before ecckd_release_scratch.
  * --------------------------------------------------------------------------------------- */
 size_t ecckd_rte_lw_scratch_bytes(int ncol, int nlay, int ngpt);
-size_t ecckd_rte_sw_scratch_bytes(int ncol, int nlay, int ngpt);
+size_t ecckd_rte_sw_scratch_bytes(int ncol, int nlay, int ngpt);   /* (two-pass solver: "sw_solver" = 1, or more than 60 layers) */
+/* What the tail splits ("lw_tail_split", "sw_tail_split") of a call of this shape would take on top, with the
+ * solver options as they are now (0: the call would not split). */
+size_t ecckd_rte_lw_tail_scratch_bytes(int device, int ncol, int nlay, int ngpt, int n_gauss_angles, int single_precision);
+size_t ecckd_rte_sw_tail_scratch_bytes(int device, int ncol, int nlay, int ngpt);
 int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t bytes);
 int ecckd_release_scratch(int device);
 

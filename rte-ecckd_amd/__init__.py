@@ -167,6 +167,10 @@ def lib():
     for f in ("ecckd_rte_lw_scratch_bytes", "ecckd_rte_sw_scratch_bytes"):
         getattr(L, f).restype = C.c_size_t
         getattr(L, f).argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ecckd_rte_sw_tail_scratch_bytes.restype = C.c_size_t
+    L.ecckd_rte_sw_tail_scratch_bytes.argtypes = [C.c_int] * 4
+    L.ecckd_rte_lw_tail_scratch_bytes.restype = C.c_size_t
+    L.ecckd_rte_lw_tail_scratch_bytes.argtypes = [C.c_int] * 6
     L.ecckd_set_stream_scratch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     L.ecckd_release_scratch.argtypes = [C.c_int]
     _lib = L
@@ -228,6 +232,15 @@ def rte_sw_scratch_bytes(ncol, nlay, ngpt):
 
 def rte_lw_scratch_bytes(ncol, nlay, ngpt):
     return int(lib().ecckd_rte_lw_scratch_bytes(int(ncol), int(nlay), int(ngpt)))
+
+
+def rte_sw_tail_scratch_bytes(ncol, nlay, ngpt, device=0):
+    return int(lib().ecckd_rte_sw_tail_scratch_bytes(int(device), int(ncol), int(nlay), int(ngpt)))
+
+
+def rte_lw_tail_scratch_bytes(ncol, nlay, ngpt, n_gauss_angles=1, single_precision=False, device=0):
+    return int(lib().ecckd_rte_lw_tail_scratch_bytes(int(device), int(ncol), int(nlay), int(ngpt), int(n_gauss_angles),
+                                                     int(bool(single_precision))))
 
 
 def set_stream_scratch(buffer, device=None, stream=None):
@@ -714,18 +727,43 @@ class GasOpticsEcckd:
     def gas_optics_ext(self, play, plev, tlay, gas_desc, optical_props, toa_src, col_dry=None):
         nlay, ncol = tlay.shape
         ng = self.get_ngpt()
+        """float64 arrays -> ecckd_gas_optics_sw; float32 arrays -> ecckd_gas_optics_sw_f32."""
         two = isinstance(optical_props, OpticalProps2str)
+        f32 = _is_f32(plev)
         try:
             space = _space_of([plev, tlay, optical_props.tau, toa_src])
-            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space)
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space, f32)
         except KeyError as e:
             return str(e.args[0])
-        rc = lib().ecckd_gas_optics_sw(
-            self._need(), ncol, nlay, _ptr(plev, (nlay + 1, ncol), "plev"), _ptr(tlay, (nlay, ncol), "tlay"),
-            n, names, ptrs, cs, ls, sc, _ptr(optical_props.tau, (ng, nlay, ncol), "tau"),
-            _ptr(optical_props.ssa, (ng, nlay, ncol), "ssa") if two else None,
-            _ptr(optical_props.g, (ng, nlay, ncol), "g") if two else None,
-            _ptr(toa_src, (ng, ncol), "toa_src"), space, _stream(space))
+        P = lambda a, shape, what: _ptr(a, shape, what, f32)
+        rc = (lib().ecckd_gas_optics_sw_f32 if f32 else lib().ecckd_gas_optics_sw)(
+            self._need(), ncol, nlay, P(plev, (nlay + 1, ncol), "plev"), P(tlay, (nlay, ncol), "tlay"),
+            n, names, ptrs, cs, ls, sc, P(optical_props.tau, (ng, nlay, ncol), "tau"),
+            P(optical_props.ssa, (ng, nlay, ncol), "ssa") if two else None,
+            P(optical_props.g, (ng, nlay, ncol), "g") if two else None,
+            P(toa_src, (ng, ncol), "toa_src"), space, _stream(space))
+        return last_error() if rc else ""
+
+    def sw_fluxes(self, plev, tlay, gas_desc, top_at_1, mu0, sfc_alb_dir, sfc_alb_dif, fluxes, toa_scale=None):
+        """``ecckd_sw_fluxes`` (float32 arrays: ``_f32``): gas optics + rte_sw in one call for hosts that only need
+        broadband fluxes -- the total optical depth alone goes through (library-owned) memory, the solver derives
+        ssa, g = 0 and the incoming beam from plev and the model's tables as gas_optics_ext does.  ``toa_scale``
+        ``(ncol,)``: the drivers' rescaling of the incoming beam (total solar irradiance), or None."""
+        nlay, ncol = tlay.shape
+        nband = self.get_nband()
+        f32 = _is_f32(plev)
+        try:
+            space = _space_of([plev, tlay, mu0, toa_scale, sfc_alb_dir, sfc_alb_dif, fluxes.flux_up, fluxes.flux_dn])
+            n, names, ptrs, cs, ls, sc, keep = self._gas_args(gas_desc, ncol, nlay, space, f32)
+        except KeyError as e:
+            return str(e.args[0])
+        P = lambda a, shape, what: _ptr(a, shape, what, f32)
+        rc = (lib().ecckd_sw_fluxes_f32 if f32 else lib().ecckd_sw_fluxes)(
+            self._need(), ncol, nlay, P(plev, (nlay + 1, ncol), "plev"), P(tlay, (nlay, ncol), "tlay"), n, names, ptrs, cs,
+            ls, sc, int(bool(top_at_1)), P(mu0, (ncol,), "mu0"), P(toa_scale, (ncol,), "toa_scale"),
+            P(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"), P(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"),
+            P(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), P(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
+            P(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))
         return last_error() if rc else ""
 
 
@@ -745,7 +783,7 @@ def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1,
     take the single-precision entry point.  ``shared_levels=True`` asserts that the level sources hold
     one value per level (``sources.levels_shared``, set by ecckd's gas_optics) and takes
     ``ecckd_rte_lw_shared_levels`` (fp64 only).  ``inc_flux`` ``(ngpt, ncol)``: incident diffuse flux at the
-    top of the domain (rte_lw's optional argument; ``ecckd_rte_lw_inc_flux``, fp64, generic solver)."""
+    top of the domain (rte_lw's optional argument; ``ecckd_rte_lw_inc_flux`` / ``_f32``, generic solver)."""
     ng, nlay, ncol = optical_props.tau.shape
     b2g = np.ascontiguousarray(optical_props.band2gpt, dtype=np.int32)
     nband = b2g.shape[0]
@@ -770,17 +808,18 @@ def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1,
     if shared_levels and f32:
         return "rte_lw: shared_levels is implemented for float64 arrays"
     if inc_flux is not None:
-        if f32 or shared_levels:
-            return "rte_lw: inc_flux is implemented for float64 arrays and the generic solver"
+        if shared_levels:
+            return "rte_lw: inc_flux is implemented for the generic solver"
         space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, inc_flux, fluxes.flux_up, fluxes.flux_dn])
-        rc = lib().ecckd_rte_lw_inc_flux(
-            int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), _ptr(optical_props.tau),
-            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
-            _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
-            _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
-            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
-            _ptr(sfc_emis, (ncol, nband), "sfc_emis"), _ptr(inc_flux, (ng, ncol), "inc_flux"),
-            _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
+        Pi = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
+        rc = (lib().ecckd_rte_lw_inc_flux_f32 if f32 else lib().ecckd_rte_lw_inc_flux)(
+            int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), Pi(optical_props.tau),
+            Pi(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            Pi(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            Pi(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            Pi(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
+            Pi(sfc_emis, (ncol, nband), "sfc_emis"), Pi(inc_flux, (ng, ncol), "inc_flux"),
+            Pi(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), Pi(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
             space, _stream(space))
         return last_error() if rc else ""
     fn = lib().ecckd_rte_lw_f32 if f32 else (lib().ecckd_rte_lw_shared_levels if shared_levels else lib().ecckd_rte_lw)
@@ -820,12 +859,14 @@ def rte_sw(optical_props, top_at_1, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, flu
             opt(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), opt(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
             opt(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))
         return last_error() if rc else ""
-    rc = lib().ecckd_rte_sw(
-        int(dev), ncol, nlay, ng, int(bool(top_at_1)), _ptr(optical_props.tau),
-        _ptr(optical_props.ssa, (ng, nlay, ncol), "ssa"), _ptr(optical_props.g, (ng, nlay, ncol), "g"),
-        _ptr(mu0, (ncol,), "mu0"), _ptr(toa_flux, (ng, ncol), "toa_flux"), nband,
-        C.c_void_p(b2g.ctypes.data), _ptr(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"),
-        _ptr(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"), _ptr(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
-        _ptr(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
-        _ptr(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))
+    f32 = _is_f32(optical_props.tau)   # float32 arrays take ecckd_rte_sw_f32
+    P = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
+    rc = (lib().ecckd_rte_sw_f32 if f32 else lib().ecckd_rte_sw)(
+        int(dev), ncol, nlay, ng, int(bool(top_at_1)), P(optical_props.tau),
+        P(optical_props.ssa, (ng, nlay, ncol), "ssa"), P(optical_props.g, (ng, nlay, ncol), "g"),
+        P(mu0, (ncol,), "mu0"), P(toa_flux, (ng, ncol), "toa_flux"), nband,
+        C.c_void_p(b2g.ctypes.data), P(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"),
+        P(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"), P(fluxes.flux_up, (nlay + 1, ncol), "flux_up"),
+        P(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
+        P(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))
     return last_error() if rc else ""

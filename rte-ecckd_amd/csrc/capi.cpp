@@ -190,8 +190,9 @@ thread_local const double *g_inc_flux = nullptr;   // set by ecckd_rte_lw_inc_fl
 // set by the *_byband entry points around the per-band solver calls: band of every g-point of the sub-range
 thread_local int g_band_override = -1;
 // set by ecckd_sw_fluxes around ecckd_rte_sw: the solver derives ssa / g / toa itself (RteSwArgs::derive)
-struct SwDerive { const double *plev, *rayleigh, *solar; double gw; };
-thread_local const SwDerive *g_sw_derive = nullptr;   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
+struct SwDerive { const double *plev, *rayleigh, *solar, *toa_scale; double gw; };
+thread_local const SwDerive *g_sw_derive = nullptr;
+thread_local double *g_sw_partials = nullptr;   // ... and the room for the solver's partial sums inside the caller's scratch block   // set by ecckd_rte_lw_shared_levels around ecckd_rte_lw
 // ecckd_gas_optics_plan(): when set, gas_optical_depth_dev() records its decisions here and launches nothing
 struct PlanRecord {
   const int *is_scalar = nullptr;   // per gas of the list: its mole fraction would be passed as one number
@@ -370,7 +371,7 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
     a.tau = tau;
     const bool last = pos >= seq.size();
     if (sw && last) {
-      a.rayleigh = m->dbuf + m->off_rayleigh;
+      a.rayleigh = g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_rayleigh) : m->dbuf + m->off_rayleigh;
       a.ssa = ssa;
       a.g = g;
     }
@@ -396,9 +397,9 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
         if (planck_done) *planck_done = true;
       }
       fa.f32 = g_f32;
-      if (g_f32 && (fa.mode != 1 || !last))
-        return fail("ecckd: single precision is implemented for the fused longwave gas optics only (this model/"
-                    "gas list needs the multi-pass or unfused path)");
+      if (g_f32 && ((fa.mode != 1 && fa.mode != 2) || !last || !first_pass))
+        return fail("ecckd: single precision is implemented for one-pass gas optics (fused longwave, shortwave); this "
+                    "model / gas list needs the multi-pass or unfused path");
       if (g_plan) {
         FusedPlan fp;
         HIPCHK(prepare_gas_fused(fa, fp));
@@ -596,6 +597,25 @@ size_t ecckd_rte_sw_scratch_bytes(int ncol, int nlay, int ngpt) {
   return ncol > 0 && nlay > 0 ? ecckd::rte_sw_scratch_bytes(ncol, nlay, ngpt) : 0;
 }
 
+size_t ecckd_rte_sw_tail_scratch_bytes(int device, int ncol, int nlay, int ngpt) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || device < 0 || device >= 16 || !g_opt.sw_tail_split.load()) return 0;
+  ecckd::RteSwArgs a{};
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt;
+  if (g_opt.sw_solver.load() == 0 && ecckd::rte_sw_sys_applies(a)) return ecckd::rte_sw_sys_plan(a, simd_slots(device) / 4);
+  long first = -1;
+  size_t at = 0;
+  return ecckd::rte_sw_tail_plan(a, &first, &at);
+}
+size_t ecckd_rte_lw_tail_scratch_bytes(int device, int ncol, int nlay, int ngpt, int n_gauss_angles, int single_precision) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || device < 0 || device >= 16 || !g_opt.lw_tail_split.load()) return 0;
+  if (n_gauss_angles < 1 || n_gauss_angles > 4) return 0;
+  ecckd::RteLwArgs a{};
+  a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.nmus = n_gauss_angles; a.f32 = single_precision ? 1 : 0;
+  a.use_split = g_opt.lw_solver.load();
+  long first = -1;
+  return ecckd::rte_lw_tail_plan(a, simd_slots(device), &first);
+}
+
 int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t bytes) {
   if (device < 0 || device >= 16) return fail("ecckd_set_stream_scratch: bad device ordinal");
   if ((buffer == nullptr) != (bytes == 0)) return fail("ecckd_set_stream_scratch: buffer and size must both be given, or neither");
@@ -603,7 +623,7 @@ int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t byte
   std::lock_guard<std::mutex> lock(pool.mu);
   ScratchPool::Block &b = pool.live[static_cast<hipStream_t>(stream)];
   if (b.p && !b.caller_owned) pool.retired.push_back(b.p);
-  b.p = buffer; b.bytes = bytes; b.caller_owned = buffer != nullptr;
+  b.p = buffer; b.bytes = bytes; b.caller_owned = buffer != nullptr; b.captured = false;
   return 0;
 }
 
@@ -1046,7 +1066,8 @@ static int gas_optics_sw_dev(const ecckd_model *m, int ncol, int nlay, const dou
                             two_stream ? g : nullptr, nullptr, nullptr, stream))   // :449-460
     return 1;
   if (!two_stream) return 0;   // caller reports :461-463 after tau has been written
-  HIPCHK(ecckd::launch_toa_src(m->dbuf + m->off_solar, ncol, m->ng, toa_src, stream));   // :468-472
+  HIPCHK(ecckd::launch_toa_src(g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + m->off_solar) : m->dbuf + m->off_solar, ncol,
+                               m->ng, toa_src, g_f32, stream));   // :468-472
   return 0;
 }
 
@@ -1281,6 +1302,7 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   if (g_sw_derive) {   // ecckd_sw_fluxes: ssa / g / toa derived inside the solver (RteSwArgs::derive)
     a.derive = 1;
     a.plev = g_sw_derive->plev; a.rayleigh = g_sw_derive->rayleigh; a.solar = g_sw_derive->solar; a.gw = g_sw_derive->gw;
+    a.toa_scale = g_sw_derive->toa_scale;
   }
   const size_t n3 = (size_t)ncol * nlay * ngpt, n2l = (size_t)ncol * (nlay + 1);
   const hipStream_t launch_stream = memspace == ECCKD_DEVICE ? static_cast<hipStream_t>(stream) : nullptr;
@@ -1294,8 +1316,9 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
     if (g_opt.sw_tail_split.load()) {
       const size_t need = ecckd::rte_sw_sys_plan(a, cus);
       if (need) {
-        if (void *sp = stream_scratch_optional(device, launch_stream, need, lease)) a.partials = static_cast<double *>(sp);
-        else { a.sys_tail_first = -1; a.sys_gchunk = 0; }
+        if (g_sw_derive) a.partials = g_sw_partials;   // (ecckd_sw_fluxes sized its block with ecckd_rte_sw_tail_scratch_bytes)
+        else if (void *sp = stream_scratch_optional(device, launch_stream, need, lease)) a.partials = static_cast<double *>(sp);
+        if (!a.partials) { a.sys_tail_first = -1; a.sys_gchunk = 0; }
       }
     }
   } else {
@@ -1634,6 +1657,138 @@ int ecckd_lw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *pl
   if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
   HIPCHK(hipStreamSynchronize(s));
   return 0;
+}
+
+// ---- single-precision flavours of the shortwave pair and of the incident-flux longwave solver ----
+
+int ecckd_gas_optics_sw_f32(const ecckd_model_t *m, int ncol, int nlay, const float *plev, const float *tlay, int ngas,
+                            const char *gas_names, const float *const *vmr, const long long *vmr_col_stride,
+                            const long long *vmr_lay_stride, const double *vmr_scalar, float *tau, float *ssa, float *g,
+                            float *toa_src, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_gas_optics_sw(m, ncol, nlay, c(plev), c(tlay), ngas, gas_names, reinterpret_cast<const double *const *>(vmr),
+                             vmr_col_stride, vmr_lay_stride, vmr_scalar, w(tau), w(ssa), w(g), w(toa_src), memspace, stream);
+}
+
+int ecckd_rte_sw_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, const float *tau, const float *ssa, const float *g,
+                     const float *mu0, const float *toa_flux, int nband, const int *band2gpt, const float *sfc_alb_dir,
+                     const float *sfc_alb_dif, float *flux_up, float *flux_dn, float *flux_dir, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_rte_sw(device, ncol, nlay, ngpt, top_at_1, c(tau), c(ssa), c(g), c(mu0), c(toa_flux), nband, band2gpt,
+                      c(sfc_alb_dir), c(sfc_alb_dif), w(flux_up), w(flux_dn), w(flux_dir), memspace, stream);
+}
+
+int ecckd_rte_lw_inc_flux_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles, const float *tau,
+                              const float *lay_source, const float *lev_source_inc, const float *lev_source_dec,
+                              const float *sfc_source, int nband, const int *band2gpt, const float *sfc_emis,
+                              const float *inc_flux, float *flux_up, float *flux_dn, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_rte_lw_inc_flux(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, c(tau), c(lay_source), c(lev_source_inc),
+                               c(lev_source_dec), c(sfc_source), nband, band2gpt, c(sfc_emis), c(inc_flux), w(flux_up),
+                               w(flux_dn), memspace, stream);
+}
+
+// ---- fused shortwave: total optical depth only between the kernels (SURVEY 8(f) rank 4 for the shortwave) ----
+
+int ecckd_sw_fluxes(const ecckd_model_t *m, int ncol, int nlay, const double *plev, const double *tlay, int ngas,
+                    const char *gas_names, const double *const *vmr, const long long *vmr_col_stride,
+                    const long long *vmr_lay_stride, const double *vmr_scalar, int top_at_1, const double *mu0,
+                    const double *toa_scale, const double *sfc_alb_dir, const double *sfc_alb_dif, double *flux_up,
+                    double *flux_dn, double *flux_dir, int memspace, void *stream) {
+  if (check_model(m) || check_gas_optics_dims(ncol, nlay)) return 1;
+  if (!m->has_solar) return fail("ecckd_sw_fluxes: model has no solar table (longwave model?)");
+  if (!plev || !tlay || !mu0 || !sfc_alb_dir || !sfc_alb_dif || !flux_up || !flux_dn || (ngas > 0 && !gas_names))
+    return fail("ecckd_sw_fluxes: null argument");
+  if (g_arith.load() != 0) return fail("ecckd_sw_fluxes: needs the fast arithmetic mode (ecckd_set_arithmetic(0))");
+  if (nlay > 60 || g_opt.sw_solver.load() != 0)
+    return fail("ecckd_sw_fluxes: needs the layer-systolic shortwave solver (sw_solver = 0, at most 60 layers)");
+  HIPCHK(hipSetDevice(m->device));
+  if (ncol == 0) return 0;
+  const GasDesc gd{ngas, gas_names, vmr, vmr_col_stride, vmr_lay_stride, vmr_scalar};
+  const size_t n2 = (size_t)ncol * nlay, n2l = (size_t)ncol * (nlay + 1), n3 = n2 * m->ng;
+  // :107 / :314 with default-real literals (:51-52), as gas_optical_depth_dev computes it
+  double gw = 1. / ((double)9.80665f * (double)0.001f * (double)28.970f);
+  if (g_f32) gw = (double)(1.f / (9.80665f * 0.001f * 28.970f));
+  auto tabs = [&](size_t off) { return g_f32 ? reinterpret_cast<const double *>(m->dbuf32 + off) : m->dbuf + off; };
+  struct Scope {
+    explicit Scope(const SwDerive *d) { g_sw_derive = d; }
+    ~Scope() { g_sw_derive = nullptr; }
+  };
+  if (memspace == ECCKD_DEVICE) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void *tau_p = nullptr;   // tau lives in the stream's scratch block between the two kernels; the solver's partial sums behind it
+    ScratchLease lease;
+    const size_t tau_bytes = align256(n3 * esz());
+    const size_t tail = ecckd_rte_sw_tail_scratch_bytes(m->device, ncol, nlay, m->ng);
+    if (stream_scratch(m->device, st, tau_bytes + tail, &tau_p, lease)) return 1;
+    double *d_tau = static_cast<double *>(tau_p);
+    // gas_optics_ext's tau (:449-456) without ssa / g: the total optical depth, gases + Rayleigh
+    if (gas_optical_depth_dev(m, ncol, nlay, plev, tlay, gd, d_tau, true, nullptr, nullptr, nullptr, nullptr, st)) return 1;
+    const SwDerive dv{plev, tabs(m->off_rayleigh), tabs(m->off_solar), toa_scale, gw};
+    Scope scope(&dv);
+    g_sw_partials = tail ? reinterpret_cast<double *>(static_cast<char *>(tau_p) + tau_bytes) : nullptr;
+    const int rc = ecckd_rte_sw(m->device, ncol, nlay, m->ng, top_at_1, d_tau, nullptr, nullptr, mu0, nullptr, m->nband,
+                                m->band2gpt.data(), sfc_alb_dir, sfc_alb_dif, flux_up, flux_dn, flux_dir, ECCKD_DEVICE, stream);
+    g_sw_partials = nullptr;
+    return rc;
+  }
+  if (memspace != ECCKD_HOST) return fail("ecckd: bad memspace");
+  ecckd_model *mm = const_cast<ecckd_model *>(m);
+  std::lock_guard<std::mutex> lock(mm->mu);
+  hipStream_t s = mm->host_stream;
+  const size_t tail = ecckd_rte_sw_tail_scratch_bytes(m->device, ncol, nlay, m->ng);
+  const size_t need = align256(n2l * esz()) * 4 + align256(n2 * esz()) + align256((size_t)ncol * esz()) * 2 +
+                      staged_gas_bytes(gd, ncol, nlay) + align256((size_t)ncol * m->nband * esz()) * 2 + align256(n3 * esz()) +
+                      align256(tail);
+  if (need > mm->arena_bytes) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (mm->arena) { HIPCHK(hipFree(mm->arena)); mm->arena = nullptr; mm->arena_bytes = 0; }
+    HIPCHK(hipMalloc(&mm->arena, need));
+    mm->arena_bytes = need;
+  }
+  Bump b(mm->arena);
+  double *d_plev = b.take(n2l), *d_tlay = b.take(n2), *d_mu0 = b.take(ncol), *d_scale = b.take(ncol);
+  double *d_up = b.take(n2l), *d_dn = b.take(n2l), *d_dir = b.take(n2l);
+  double *d_ad = b.take((size_t)ncol * m->nband), *d_af = b.take((size_t)ncol * m->nband);
+  if (h2d(d_plev, plev, n2l, s) || h2d(d_tlay, tlay, n2, s) || h2d(d_mu0, mu0, ncol, s) ||
+      h2d(d_ad, sfc_alb_dir, (size_t)ncol * m->nband, s) || h2d(d_af, sfc_alb_dif, (size_t)ncol * m->nband, s))
+    return 1;
+  if (toa_scale && h2d(d_scale, toa_scale, ncol, s)) return 1;
+  StagedGases sg;
+  if (stage_gases(gd, ncol, nlay, b, s, sg)) return 1;
+  double *d_tau = b.take(n3);
+  double *d_part = tail ? b.take((tail + esz() - 1) / esz()) : nullptr;
+  if (gas_optical_depth_dev(m, ncol, nlay, d_plev, d_tlay, sg.gd, d_tau, true, nullptr, nullptr, nullptr, nullptr, s)) return 1;
+  const SwDerive dv{d_plev, tabs(m->off_rayleigh), tabs(m->off_solar), toa_scale ? d_scale : nullptr, gw};
+  Scope scope(&dv);
+  g_sw_partials = d_part;
+  const int rc = ecckd_rte_sw(m->device, ncol, nlay, m->ng, top_at_1, d_tau, nullptr, nullptr, d_mu0, nullptr, m->nband,
+                              m->band2gpt.data(), d_ad, d_af, d_up, d_dn, flux_dir ? d_dir : nullptr, ECCKD_DEVICE, s);
+  g_sw_partials = nullptr;
+  if (rc) return 1;
+  if (d2h(flux_up, d_up, n2l, s) || d2h(flux_dn, d_dn, n2l, s)) return 1;
+  if (flux_dir && d2h(flux_dir, d_dir, n2l, s)) return 1;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ecckd_sw_fluxes_f32(const ecckd_model_t *m, int ncol, int nlay, const float *plev, const float *tlay, int ngas,
+                        const char *gas_names, const float *const *vmr, const long long *vmr_col_stride,
+                        const long long *vmr_lay_stride, const double *vmr_scalar, int top_at_1, const float *mu0,
+                        const float *toa_scale, const float *sfc_alb_dir, const float *sfc_alb_dif, float *flux_up,
+                        float *flux_dn, float *flux_dir, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_sw_fluxes(m, ncol, nlay, c(plev), c(tlay), ngas, gas_names, reinterpret_cast<const double *const *>(vmr),
+                         vmr_col_stride, vmr_lay_stride, vmr_scalar, top_at_1, c(mu0), c(toa_scale), c(sfc_alb_dir),
+                         c(sfc_alb_dif), w(flux_up), w(flux_dn), w(flux_dir), memspace, stream);
 }
 
 // ---- spectral (per-band) fluxes: ty_fluxes_byband of RTE-RRTMGP ----

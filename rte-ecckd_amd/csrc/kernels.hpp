@@ -150,6 +150,7 @@ struct RteSwArgs {
   // expressions (src/gas_optics_ecckd.f90:313-317,455-472).  derive != 0 selects it; ssa / g / toa are then unused.
   int derive = 0;
   const double *plev = nullptr, *rayleigh = nullptr, *solar = nullptr;   // plev(ncol,nlay+1) device; (ng) device tables
+  const double *toa_scale = nullptr;   // (ncol) or null: toa(i,g) = solar(g)*toa_scale(i), the driver's TSI rescaling (ecckd_rfmip_sw.F90:126-133)
   double gw = 0.;
 };
 
@@ -198,7 +199,7 @@ hipError_t launch_planck(PlanckArgs &a, hipStream_t s);
 hipError_t launch_planck_pair(const PlanckArgs &a, int f32, hipStream_t s);
 size_t planck_pair_lds_bytes(int ng, int ntp, int f32);
 UDiv make_udiv(double d, int f32);
-hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s);
+hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, int f32, hipStream_t s);
 // out(i) = sum_b planes(i, b): broadband from per-band fluxes
 hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double *out, int f32, hipStream_t s);
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);

@@ -948,7 +948,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
     long per_block = (ntiles + chunks - 1) / chunks;
     t.seg = (int)(per_block < kSeg ? kSeg : (per_block > kSegMax ? kSegMax : per_block));
   }
-  if (a.f32 && a.mode != MODE_LW) return hipErrorNotSupported;   // single precision: the longwave fused path only
+  if (a.f32 && a.mode == MODE_TAU) return hipErrorNotSupported;   // single precision: the one-pass longwave and shortwave paths
   plan.lds_bytes = lds;
   plan.anyclamp = anyclamp ? 1 : 0;
   plan.GC = GC; plan.NB = NB; plan.merged = t.merge_slot >= 0 ? t.nmerge : 0;
@@ -962,6 +962,7 @@ hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   if (e != hipSuccess || plan.empty) return e;
   const TauArgs &t = a.tau;
   const bool anyclamp = plan.anyclamp != 0;
+  if (a.f32 && a.mode == MODE_SW) return launch_mode<float, MODE_SW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
   if (a.f32) return launch_mode<float, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
   if (a.mode == MODE_LW) return launch_mode<double, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
   if (a.mode == MODE_SW) return launch_mode<double, MODE_SW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);

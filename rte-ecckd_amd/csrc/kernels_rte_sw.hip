@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256) rte_sw_tail_reduce(const double *partials
   if (flux_dir) flux_dir[q] = (real)dir;
 }
 
-__global__ void toa_src_kernel(const double *solar, int ncol, int ng, double *toa) {
+template <typename real>
+__global__ void toa_src_kernel(const real *solar, int ncol, int ng, real *toa) {
   const long n = (long)ncol * ng;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x)
     toa[q] = solar[q / ncol];   // src/gas_optics_ecckd.f90:468-472
@@ -373,12 +374,16 @@ hipError_t launch_rte_sw_tail_reduce(const RteSwArgs &a, int nchunks, int cw, lo
   return hipGetLastError();
 }
 
-hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, hipStream_t s) {
+hipError_t launch_toa_src(const double *solar, int ncol, int ng, double *toa_src, int f32, hipStream_t s) {
   const long n = (long)ncol * ng;
   if (n <= 0) return hipSuccess;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(toa_src_kernel, dim3((unsigned)blocks), dim3(256), 0, s, solar, ncol, ng, toa_src);
+  if (f32)
+    hipLaunchKernelGGL(toa_src_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(solar), ncol, ng,
+                       reinterpret_cast<float *>(toa_src));
+  else
+    hipLaunchKernelGGL(toa_src_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, solar, ncol, ng, toa_src);
   return hipGetLastError();
 }
 

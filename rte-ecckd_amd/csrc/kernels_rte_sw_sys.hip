@@ -185,7 +185,8 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       pb0 = P(a.alb_dif)[band + (long)a.nband * cc];
       pb1 = P(a.alb_dir)[band + (long)a.nband * cc];   // src_sfc = F_dir(sfc) * sfc_alb_dir
     };
-    auto load_toa = [&](int g) { ptoa = DERIVE ? P(a.solar)[g] : at(P(a.toa) + (long)ncol * g); };
+    const real tscale = (DERIVE && a.toa_scale) ? P(a.toa_scale)[cc] : real(1);
+    auto load_toa = [&](int g) { ptoa = DERIVE ? P(a.solar)[g] * tscale : at(P(a.toa) + (long)ncol * g); };
     auto load_props = [&](int g) {
       // (no select on a value just requested -- it would wait for the load on the spot: a layer this wave does not
       // own keeps whatever its registers hold, nothing reads them)

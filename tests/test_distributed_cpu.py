@@ -66,3 +66,24 @@ def test_synthetic_generator_is_shardable():
     # known value of the counter-based generator (guards the bit-reproducibility contract)
     assert synthetic.uniform(0, 1, 0) == synthetic.uniform(0, 1, 0)
     assert synthetic.uniform(5, 2, 9) != synthetic.uniform(5, 2, 10)
+
+
+def test_bench_self_launch_reaches_the_ranks_without_a_gpu(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent must start the ranks itself (a child
+    `python -m torch.distributed.run`) and hand their exit code on.  On this GPU-less container every rank stops at
+    "bench.py needs a GPU": seeing THAT message from two ranks (and rc != 0) proves the launch path up to the first GPU
+    call; tests/test_gpu_round3.py::test_bench_launches_its_own_ranks runs it to the JSON line on the GPU box."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: covered by the gpu test")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ncol", "64",
+                        "--cpu-seconds", "0", "--no-side", "--rehearse-on-one-gpu"], capture_output=True, text=True, env=env,
+                       cwd=str(tmp_path), timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]

@@ -199,3 +199,227 @@ def test_host_threads_share_the_solver_scratch(pkg, gpu, oracle_mod):
         th.join()
     assert not errors, errors[:3]
     pkg.release_scratch(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused shortwave path (ecckd_sw_fluxes), single precision outside the longwave fused path
+# ------------------------------------------------------------------------------------------------
+SW_NAMES = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
+
+
+@pytest.fixture(scope="module")
+def sw(pkg, gpu, oracle_mod):
+    from conftest import SW_WIDE
+    k = pkg.GasOpticsEcckd()
+    assert k.load(SW_WIDE, device=0) == ""
+    return k, oracle_mod.CkdModel(SW_WIDE)
+
+
+def sw_columns(k, c0, ncol, rng):
+    from rte_ecckd_amd import synthetic
+    cols = synthetic.columns(c0, ncol, k.get_press_min(), shortwave=True)
+    nband = k.get_nband()
+    cols["alb_dir"] = rng.uniform(0.02, 0.6, (ncol, nband))
+    cols["alb_dif"] = rng.uniform(0.02, 0.6, (ncol, nband))
+    cols["scale"] = rng.uniform(0.97, 1.03, ncol)
+    return cols
+
+
+def sw_api_path(pkg, k, cols, to, dtype, top_at_1=True, scale=False):
+    """gas_optics + (driver-side rescaling of toa_flux) + rte_sw through the API objects; returns numpy fluxes."""
+    import helpers
+    ncol = cols["plev"].shape[1]
+    nlay, ng = cols["tlay"].shape[0], k.get_ngpt()
+    gc = helpers.product_gas_concs(pkg, cols, to, SW_NAMES)
+    like = to(np.zeros(1, dtype=dtype))
+    op = pkg.OpticalProps2str(); op.alloc_2str(ncol, nlay, k, like=like)
+    toa = to(np.empty((ng, ncol), dtype=dtype))
+    assert k.gas_optics(None, to(cols["plev"]), to(cols["tlay"]), gc, op, toa) == ""
+    if scale:
+        toa = toa * to(cols["scale"])[None, :]           # ecckd_rfmip_sw.F90:126-133
+    fl = pkg.FluxesBroadband(*(to(np.empty((nlay + 1, ncol), dtype=dtype)) for _ in range(3)))
+    assert pkg.rte_sw(op, top_at_1, to(cols["mu0"]), toa, to(cols["alb_dir"]), to(cols["alb_dif"]), fl) == ""
+    back = (lambda a: a.cpu().numpy()) if hasattr(fl.flux_up, "cpu") else (lambda a: a)
+    return [back(fl.flux_up), back(fl.flux_dn), back(fl.flux_dn_dir)], op, toa
+
+
+def sw_fused_path(pkg, k, cols, to, dtype, top_at_1=True, scale=False, with_dir=True):
+    import helpers
+    ncol = cols["plev"].shape[1]
+    nlay = cols["tlay"].shape[0]
+    gc = helpers.product_gas_concs(pkg, cols, to, SW_NAMES)
+    fl = pkg.FluxesBroadband(*(to(np.full((nlay + 1, ncol), -1, dtype=dtype)) for _ in range(3 if with_dir else 2)))
+    assert k.sw_fluxes(to(cols["plev"]), to(cols["tlay"]), gc, top_at_1, to(cols["mu0"]), to(cols["alb_dir"]), to(cols["alb_dif"]),
+                       fl, toa_scale=to(cols["scale"]) if scale else None) == ""
+    back = (lambda a: a.cpu().numpy()) if hasattr(fl.flux_up, "cpu") else (lambda a: a)
+    return [back(fl.flux_up), back(fl.flux_dn)] + ([back(fl.flux_dn_dir)] if with_dir else [])
+
+
+@pytest.mark.parametrize("ncol,top_at_1,scale", [(333, True, False), (1500, True, True), (20000, True, False), (700, False, True)])
+def test_fused_sw_path(pkg, gpu, oracle_mod, sw, ncol, top_at_1, scale):
+    """ecckd_sw_fluxes -- gas optics writes the total optical depth only, the solver derives ssa = tau_rayleigh/tau,
+    g = 0 and the incoming beam as gas_optics_ext does (src/gas_optics_ecckd.f90:455-472) -- against gas_optics +
+    rte_sw through the API (bit-identical fluxes: the same arithmetic per cell) and against the oracle pair; device
+    and host arrays, with and without the direct flux, the drivers' rescaling of the incoming beam, and (the model's
+    layers reversed) the bottom-up orientation."""
+    import torch
+    import helpers
+    k, m = sw
+    rng = np.random.default_rng(ncol)
+    cols = sw_columns(k, 7 * ncol, ncol, rng)
+    if not top_at_1:   # bottom-up arrays: reverse the vertical axis of every profile.  (gas_optics takes the layer mass from
+        # plev(l+1) - plev(l), src/gas_optics_ecckd.f90:143,313 -- negative here, optical depths clamped or negative as in the
+        # reference: this case only checks that the fused path follows the two calls bit for bit in this orientation too)
+        for n in ("plev", "tlay", "tlev", "h2o", "o3"):
+            cols[n] = np.ascontiguousarray(cols[n][::-1])
+    t = T(gpu)
+    api, op, toa = sw_api_path(pkg, k, cols, t, np.float64, top_at_1, scale)
+    fused = sw_fused_path(pkg, k, cols, t, np.float64, top_at_1, scale)
+    for a, b in zip(api, fused):
+        assert np.array_equal(a, b, equal_nan=True)
+    two = sw_fused_path(pkg, k, cols, t, np.float64, top_at_1, scale, with_dir=False)
+    assert np.array_equal(two[0], fused[0], equal_nan=True) and np.array_equal(two[1], fused[1], equal_nan=True)
+    if ncol <= 1500:
+        host = sw_fused_path(pkg, k, cols, np.ascontiguousarray, np.float64, top_at_1, scale)
+        for a, b in zip(host, fused):
+            assert np.array_equal(a, b, equal_nan=True)
+    if ncol <= 1500 and top_at_1:
+        otau, ossa, og, otoa, oerr = oracle_mod.gas_optics_ext(m, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, SW_NAMES))
+        assert oerr == ""
+        if scale:
+            otoa = otoa * cols["scale"][None, :]
+        g2b = m.gpt2band - 1
+        ref = oracle_mod.rte_sw(otau, ossa, og, cols["mu0"], otoa, np.ascontiguousarray(cols["alb_dir"][:, g2b].T),
+                                np.ascontiguousarray(cols["alb_dif"][:, g2b].T), top_at_1=top_at_1)
+        for a, b in zip(fused, ref):   # (each side on its own optical properties: see test_random_sw_gas_descriptions_and_fluxes)
+            assert np.max(np.abs(a - b)) < 10 * FLUX_ATOL
+    pkg.set_arithmetic(pkg.REFERENCE_ORDER)
+    gc = helpers.product_gas_concs(pkg, cols, t, SW_NAMES)
+    fl = pkg.FluxesBroadband(*(torch.empty((61, ncol), dtype=torch.float64, device=gpu) for _ in range(2)))
+    msg = k.sw_fluxes(t(cols["plev"]), t(cols["tlay"]), gc, top_at_1, t(cols["mu0"]), t(cols["alb_dir"]), t(cols["alb_dif"]), fl)
+    assert "fast arithmetic" in msg
+
+
+def test_single_precision_sw_path(pkg, gpu, oracle_mod, sw):
+    """float32 arrays take ecckd_gas_optics_sw_f32 / ecckd_rte_sw_f32 / ecckd_sw_fluxes_f32 (a host built with wp = real32,
+    src/gas_optics_ecckd.f90:6).  Against the fp64 oracle on the float32-rounded inputs, single-precision bars: tau 5e-5
+    relative (where tau is not tiny), ssa 5e-5 absolute, fluxes 0.05 W m-2 in 99 % of the columns and 0.5 W m-2 (of up
+    to 1 300) for the worst -- cells near the resonance k*mu0 = 1 of the two-stream direct terms lose digits to
+    1 - (k*mu0)**2 in any single-precision evaluation; the fused path gives the fluxes of the two calls bit for bit."""
+    import torch
+    import helpers
+    k, m = sw
+    ncol, nlay, ng = 900, 60, 27
+    rng = np.random.default_rng(2)
+    cols = sw_columns(k, 11, ncol, rng)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+    api, op, toa = sw_api_path(pkg, k, cols, t32, np.float32)
+    assert op.tau.dtype == torch.float32 and api[0].dtype == np.float32
+    r = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32), dtype=np.float64)
+    c32 = {n: (r(v) if isinstance(v, np.ndarray) else v) for n, v in cols.items()}
+    otau, ossa, og, otoa, oerr = oracle_mod.gas_optics_ext(m, c32["plev"], c32["tlay"], helpers.oracle_gas_items(c32, SW_NAMES))
+    g2b = m.gpt2band - 1
+    ref = oracle_mod.rte_sw(otau, ossa, og, c32["mu0"], otoa, np.ascontiguousarray(c32["alb_dir"][:, g2b].T),
+                            np.ascontiguousarray(c32["alb_dif"][:, g2b].T))
+    gt = op.tau.cpu().numpy().astype(np.float64)
+    big = otau > 1e-6 * otau.max()
+    assert np.max(np.abs(gt - otau)[big] / otau[big]) < 5e-5
+    assert np.max(np.abs(op.ssa.cpu().numpy() - ossa)) < 5e-5 and bool((op.g == 0).all())
+    assert np.max(np.abs(toa.cpu().numpy() - otoa)) < 1e-4
+    for a, b in zip(api, ref):
+        d = np.abs(a - b)
+        assert np.max(d) < 0.5 and np.percentile(d.max(axis=0), 99) < 0.05     # (per column: all, and 99 % of them)
+    fused = sw_fused_path(pkg, k, cols, t32, np.float32)
+    for a, b in zip(api, fused):
+        assert np.array_equal(a, b)
+
+
+def test_single_precision_incident_flux(pkg, gpu, oracle_mod):
+    """ecckd_rte_lw_inc_flux_f32 against the fp64 oracle on the same (float32-rounded) arrays: 2e-3 W m-2."""
+    import torch
+    rng = np.random.default_rng(12)
+    ng, nlay, ncol = 6, 60, 500
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    tau, lay, inc, dec = f(rng.uniform(0.001, 1.5, (ng, nlay, ncol))), f(rng.uniform(1, 9, (ng, nlay, ncol))), \
+        f(rng.uniform(1, 9, (ng, nlay, ncol))), f(rng.uniform(1, 9, (ng, nlay, ncol)))
+    sfc, incf, emis = f(rng.uniform(1, 9, (ng, ncol))), f(rng.uniform(0, 5, (ng, ncol))), f(rng.uniform(0.9, 1.0, (ncol, 1)))
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    op = pkg.OpticalProps1scl(); op.tau = t(tau); op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+    src = pkg.SourceFuncLW(); src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = t(lay), t(inc), t(dec), t(sfc)
+    for nmus, top in ((1, True), (3, False)):
+        fl = pkg.FluxesBroadband(torch.empty((nlay + 1, ncol), dtype=torch.float32, device=gpu),
+                                 torch.empty((nlay + 1, ncol), dtype=torch.float32, device=gpu))
+        assert pkg.rte_lw(op, top, src, t(emis), fl, n_gauss_angles=nmus, inc_flux=t(incf)) == ""
+        d = lambda a: a.astype(np.float64)
+        fu, fd = oracle_mod.rte_lw(d(tau), d(lay), d(inc), d(dec), np.repeat(d(emis).T, ng, 0), d(sfc), top_at_1=top, nmus=nmus,
+                                   inc_flux=d(incf))
+        assert np.max(np.abs(fl.flux_up.cpu().numpy() - fu)) < 2e-3 * nmus and np.max(np.abs(fl.flux_dn.cpu().numpy() - fd)) < 2e-3 * nmus
+
+
+def test_full_size_sw_properties(pkg, gpu, oracle_mod, sw):
+    """BASELINE configs[2] at full size (1e5 synthetic columns x 60 layers x 27 g-points, gas_optics + rte_sw): the oracle
+    cannot run that in seconds, so size-independent properties -- oracle spot checks at both ends and in the tail tiles,
+    calls repeat bit for bit, a column's fluxes do not depend on its position (shuffle) nor on the size of the call,
+    energy conservation bounds, the mu0 edge (sun at the horizon) and the drivers' night columns (mu0 = 1, fluxes zeroed
+    by the caller: ecckd_rfmip_sw.F90:143-145,156-161) stay finite."""
+    import helpers
+    k, m = sw
+    ncol = 100000
+    rng = np.random.default_rng(1)
+    cols = sw_columns(k, 0, ncol, rng)
+    cols["mu0"][:50] = 1e-3                 # sun at the horizon
+    cols["mu0"][50:100] = 1.0               # what the drivers put in night columns
+    t = T(gpu)
+    out, op, toa = sw_api_path(pkg, k, cols, t, np.float64)
+    again, _, _ = sw_api_path(pkg, k, cols, t, np.float64)
+    for a, b in zip(out, again):
+        assert np.array_equal(a, b)
+    up, dn, dr = out
+    assert np.all(np.isfinite(up)) and np.all(np.isfinite(dn)) and np.all(up >= 0) and np.all(dr >= 0) and np.all(dn >= dr)
+    tsi = m.solar_irradiance.sum() if hasattr(m, "solar_irradiance") else k.get_total_solar_irradiance()
+    assert np.all(dn[0] <= tsi * cols["mu0"] * (1 + 1e-12)) and np.all(up[0] <= dn[0] * (1 + 1e-12))   # nothing gains energy
+    assert np.allclose(dn[0], tsi * cols["mu0"], rtol=1e-12)
+    g2b = m.gpt2band - 1
+    for lo, hi in ((0, 128), (49990, 50040), (ncol - 200, ncol)):      # first tile, middle, the tail tiles of the last round
+        sl = slice(lo, hi)
+        sub = {n: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.shape[-1] == ncol else v)
+               for n, v in cols.items() if n not in ("alb_dir", "alb_dif")}
+        otau, ossa, og, otoa, _ = oracle_mod.gas_optics_ext(m, sub["plev"], sub["tlay"], helpers.oracle_gas_items(sub, SW_NAMES))
+        ref = oracle_mod.rte_sw(otau, ossa, og, sub["mu0"], otoa, np.ascontiguousarray(cols["alb_dir"][sl][:, g2b].T),
+                                np.ascontiguousarray(cols["alb_dif"][sl][:, g2b].T))
+        for a, b in zip(out, ref):
+            assert np.max(np.abs(a[:, sl] - b)) < 10 * FLUX_ATOL
+    # position and call size: 3000 columns taken from all over the call, shuffled, as a call of their own
+    pick = rng.permutation(ncol)[:3000]
+    sub = {}
+    for n, v in cols.items():
+        if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[1] == ncol:
+            sub[n] = np.ascontiguousarray(v[:, pick])
+        elif isinstance(v, np.ndarray) and v.shape[0] == ncol:
+            sub[n] = np.ascontiguousarray(v[pick])
+        else:
+            sub[n] = v
+    small, _, _ = sw_api_path(pkg, k, sub, t, np.float64)
+    for a, b in zip(out, small):
+        assert np.array_equal(a[:, pick], b)
+
+
+def test_bench_launches_its_own_ranks(pkg, gpu, tmp_path):
+    """`python bench.py --gpus 2` with NO launcher in front: the parent starts the ranks itself (torch.distributed.run as
+    a child, before anything touches the GPU) and passes rank 0's JSON line through.  Here both ranks sit on cuda:0
+    over gloo (--rehearse-on-one-gpu); on a node with N GPUs the same command runs one rank per GPU over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k2: v for k2, v in os.environ.items() if k2 not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ncol", "60000",
+           "--cpu-seconds", "0", "--no-side", "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ncol_total"] == 120000
+    assert len(d["per_rank_ms_per_step"]["ranks"]) == 2 and d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL
