@@ -100,17 +100,40 @@ def committed_counters(name, key, ncol):
         return None, "no committed PMC pass for this workload (%s)" % type(e).__name__
 
 
+def cgroup_cpu_quota():
+    """CPUs the cgroup of this process may use (cpu.max of cgroup v2, cfs quota of v1), or None if unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, press_min):
     """The CPU restatement (oracle/, 'port' of the reference Fortran: same per-gas passes and temporaries as
     src/gas_optics_ecckd.f90:117-240,370 plus the RTE LW recurrences) timed on this host's cores over bounded
     samples of the same synthetic columns.  Legs:
-      value          all host cores, column blocks of --cpu-block spread over OpenMP threads
-      one_thread     1 thread, block = 1 (what the reference driver does: ecckd_rfmip_lw.F90:39) and block = 1000"""
+      value          all CPUs the process may use (cgroup quota, else the visible hardware threads): column blocks spread
+                     over that many OpenMP threads, every thread re-using one arena of temporaries for all its blocks;
+                     block size = the best of a short sweep over 8 / 64 / 256
+      one_thread     1 thread, block = 1 (what the reference driver does: ecckd_rfmip_lw.F90:39) and block = 1000
+    and the ratio of the two, so that a poor all-cores figure shows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from rte_ecckd_amd import synthetic
     m = oracle.CkdModel(LW_FILE)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    # threads = the CPUs this process may actually use: the GPU boxes show all 256 hardware threads of the host but grant
+    # a cgroup quota of 16 CPUs per GPU -- 256 threads on that quota time-slice (round 2 did that: 10x one thread), and
+    # pinning them (OMP_PROC_BIND=close) made it worse (1.2x one thread, measured in round 3): threads float, one per CPU
+    cores = max(1, min(visible, int(quota + 0.5))) if quota else visible
 
     def timed(n, block, nthreads):
         cols = synthetic.columns(0, n, press_min)
@@ -128,10 +151,19 @@ def cpu_baseline(args, press_min):
         dt = timed(n, block, nthreads)
         return n, dt, n * NLAY * m.ng / dt / 1e6
 
-    block = args.cpu_block
-    n, dt, rate = leg(block, cores, args.cpu_seconds, 64 * cores)
+    # short sweep over the block size at all cores (second call of each: threads and pages are warm)
+    sweep = {}
+    blocks = (args.cpu_block,) if args.cpu_block else (8, 64, 256)
+    for blk in blocks:
+        n0 = blk * cores * 2
+        timed(n0, blk, cores)
+        sweep[blk] = n0 * NLAY * m.ng / timed(n0, blk, cores) / 1e6
+    block = max(sweep, key=sweep.get)
+    n, dt, rate = leg(block, cores, args.cpu_seconds, block * cores * 2)
     out = {"value": rate, "unit": "Mcol*lay*gpt/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-           "nproc": os.cpu_count(),
+           "nproc": os.cpu_count(), "block": block, "block_sweep_Mcell_s": {str(k): v for k, v in sweep.items()},
+           "hardware_threads_visible": visible, "cgroup_cpu_quota": quota,
+           "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
            "sample": "%d synthetic columns x %d layers x %d g-points, column blocks of %d over %d OpenMP "
                      "threads, %.1f s" % (n, NLAY, m.ng, block, cores, dt)}
     legs = {}
@@ -140,6 +172,10 @@ def cpu_baseline(args, press_min):
         legs["block_%d" % blk] = {"value": r1, "unit": "Mcol*lay*gpt/s", "cores": 1,
                                   "sample": "%d columns, blocks of %d, 1 thread, %.1f s" % (n1, blk, dt1)}
     out["one_thread"] = legs
+    best1 = max(v["value"] for v in legs.values())
+    out["scaling_vs_one_thread"] = rate / best1
+    out["scaling_note"] = ("all-CPUs rate / best 1-thread rate with %d threads (%d hardware threads visible, cgroup quota %s CPUs; "
+                           "the port streams ~380 B per cell through memory as the reference does)" % (cores, visible, quota))
     return out
 
 
@@ -346,7 +382,8 @@ def main():
     ap.add_argument("--host-sample", type=int, default=20000,
                     help="columns of the PCIe-inclusive side measurement through the ECCKD_HOST memory space "
                          "(host arrays in, host arrays out; 0 = skip).  Reported beside the headline, never as it.")
-    ap.add_argument("--cpu-block", type=int, default=8, help="columns per block in the all-cores CPU baseline leg")
+    ap.add_argument("--cpu-block", type=int, default=0,
+                    help="columns per block in the all-cores CPU baseline leg (0: the best of a sweep over 8, 64, 256)")
     ap.add_argument("--lut", choices=["fsck", "rrtmgp"], default="fsck",
                     help="LW table: fsck-tol0.0161 (32 g, headline) or rrtmgp-tol0.061 (36 g, 16 bands; BASELINE configs[4])")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
@@ -477,7 +514,7 @@ def main():
         if dom:
             traffic, tsrc = (None, "only quoted for the 1e6-column fp64 fsck workload")
             if ncol == 1000000 and args.dtype == "f64" and args.lut == "fsck" and args.arithmetic == "fast":
-                traffic, tsrc = committed_traffic("r02_hbm_traffic.json", dom)
+                traffic, tsrc = committed_traffic("r03_hbm_traffic.json", dom)
             ach = per_kernel[dom]["GBps"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
@@ -671,7 +708,7 @@ def main():
         if side and ncol == 1000000 and args.lut == "fsck" and args.dtype == "f64" and args.arithmetic == "fast":
             sw = sw_measure(100000, args.steps, args.warmup)
             out["configs_2"] = {k2: sw[k2] for k2 in ("value", "unit", "ms_per_step", "roofline", "roofline_fp64_valu", "roofline_pipeline",
-                                                      "kernels", "check_max_abs_flux_diff_vs_oracle_Wm2")}
+                                                      "kernels", "fused_sw", "check_max_abs_flux_diff_vs_oracle_Wm2")}
             out["configs_2"]["workload"] = sw["config"]["workload"]
             torch.cuda.empty_cache()
             out["configs_4"] = {dt4: lw_measure(pkg, LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061"), 1000000, dt4, args.steps,
@@ -806,13 +843,38 @@ def sw_measure(ncol, steps, warmup, solver_option=()):
     dom = max(kern, key=kern.get)
     # HBM roofline of the dominant kernel, and beside it the roofline of what actually binds rte_sw: fp64 vector
     # arithmetic.  Counters (HBM bytes, fp64 instruction counts) come from the committed rocprofv3 --pmc passes of this build.
-    ctr, csrc = committed_counters("r02_pmc_sw.json", dom, ncol)
+    # side measurement on the same resident inputs: the fused shortwave path (ecckd_sw_fluxes: 16 instead of 48 B per cell
+    # between the kernels; the solver is bound by its serial sweeps, not by HBM: reported apart from the API roofline)
+    ref_up, ref_dn = fl.flux_up.clone(), fl.flux_dn.clone()
+
+    def fstep():
+        e = k.sw_fluxes(plev, tlay, gc, True, percol["mu0"], alb, alb, fl)
+        if e:
+            raise SystemExit(e)
+    for _ in range(max(args.warmup, 1)):
+        fstep()
+    torch.cuda.synchronize()
+    L.ecckd_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fstep()
+    torch.cuda.synchronize()
+    ms_f = (time.perf_counter() - t0) / args.steps * 1e3
+    L.ecckd_prof_enable(0)
+    nk = L.ecckd_prof_report(8, names_b, ms, cnt)
+    kf = {names_b.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): ms[i] / max(cnt[i], 1) for i in range(nk)}
+    fused_sw = {"value": cells / (ms_f * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": ms_f,
+                "speedup_vs_api_pair": ms_per_step / ms_f, "kernels_avg_ms": kf, "hbm_bytes_per_cell_between_kernels": 16,
+                "max_abs_flux_diff_vs_api_path_Wm2": max(float((fl.flux_up - ref_up).abs().max()), float((fl.flux_dn - ref_dn).abs().max())),
+                "note": "ecckd_sw_fluxes: gas optics writes the total optical depth only, the solver derives ssa, g = 0 and the "
+                        "incoming beam from plev and the model's tables (src/gas_optics_ecckd.f90:455-472); same inputs, same fluxes"}
+    ctr, csrc = committed_counters("r03_pmc_sw.json", dom, ncol)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (kernels[dom]["GBps"] or 0.0) / HBM_PEAK_GBS,
                 "traffic": ctr.get("hbm_bytes_per_launch") if ctr else None, "traffic_source": csrc,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
-                "note": "rte_sw is bound by fp64 arithmetic (two exp, sqrt, three divisions per cell and pass), not by "
-                        "HBM: see roofline_fp64_valu and DESIGN.md 5.4"}
+                "note": "rte_sw (layer-systolic solver) is bound by the serial sweeps of the adding method -- one wave at a time "
+                        "holds a tile's token and issues one fp64 instruction per ~10 clocks -- not by HBM: DESIGN.md 5.4"}
     valu_roof = None
     if ctr and "SQ_INSTS_VALU_FMA_F64" in ctr:
         secs = kernels[dom]["avg_ms"] * 1e-3
@@ -846,7 +908,7 @@ def sw_measure(ncol, steps, warmup, solver_option=()):
         "roofline": roofline, "roofline_fp64_valu": valu_roof,
         "roofline_pipeline": {"bound": "hbm", "achieved": alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "kernels": kernels, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux, "cpu_baseline": None})
+        "kernels": kernels, "fused_sw": fused_sw, "check_max_abs_flux_diff_vs_oracle_Wm2": dflux, "cpu_baseline": None})
 
 
 if __name__ == "__main__":

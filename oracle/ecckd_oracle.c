@@ -27,6 +27,29 @@ static double global_weight(void) {
   return 1. / (gravity * (double)0.001f * dry_air_molar_mass);
 }
 
+/* Temporaries of the routines below (the reference's allocate / deallocate of optical_depth, layer_vmr, buffer ...:
+ * src/gas_optics_ecckd.f90:112-115,375,413,425,465).  Inside oracle_lw_pipeline every thread owns one arena that it
+ * re-uses for all its column blocks; elsewhere this is malloc / free.  (Round 2 timed the all-cores leg with ten
+ * malloc / free pairs per block inside the parallel loop: blocks of 8 columns are 0.1-0.5 MB each, beyond glibc's mmap
+ * threshold, so every one of them was an mmap / munmap system call and 256 threads queued on the address-space lock.) */
+static _Thread_local char *tl_arena = NULL;
+static _Thread_local size_t tl_cap = 0, tl_off = 0;
+static void *tmp_alloc(size_t n) {
+  if (tl_arena) {
+    const size_t a = (n + 63) & ~(size_t)63;
+    if (tl_off + a <= tl_cap) {
+      void *p = tl_arena + tl_off;
+      tl_off += a;
+      return p;
+    }
+  }
+  return malloc(n);
+}
+static void tmp_free(void *p) {
+  if (tl_arena && (char *)p >= tl_arena && (char *)p < tl_arena + tl_cap) return;   /* released with the block */
+  free(p);
+}
+
 static double dmax(double a, double b) { return a > b ? a : b; }
 static double dmin(double a, double b) { return a < b ? a : b; }
 
@@ -150,7 +173,7 @@ void oracle_calculate_rayleigh_optical_depth(const oracle_model_t *m, int ncol, 
                                              const double *plev, double *od) {
   const double gw = global_weight(); /* :314 (1./(gravity*0.001*dry_air_molar_mass)) */
   const long n2 = (long)ncol * nlay;
-  double *moles = (double *)malloc(sizeof(double) * n2);
+  double *moles = (double *)tmp_alloc(sizeof(double) * n2);
   for (int j = 0; j < nlay; ++j)
     for (int i = 0; i < ncol; ++i)
       moles[i + (long)ncol * j] =
@@ -158,7 +181,7 @@ void oracle_calculate_rayleigh_optical_depth(const oracle_model_t *m, int ncol, 
   for (int k = 0; k < m->ng; ++k)
     for (long q = 0; q < n2; ++q)
       od[q + n2 * k] = moles[q] * m->rayleigh_molar_scattering_coeff[k]; /* :316 */
-  free(moles);
+  tmp_free(moles);
 }
 
 /* trim() comparison of two blank-padded Fortran names == strcmp of the C strings. */
@@ -169,8 +192,8 @@ int oracle_gas_optical_depth(const oracle_model_t *m, int ncol, int nlay, const 
                              const double *tlay, const oracle_gas_concs_t *gc, double *tau,
                              char *errmsg) {
   const long n2 = (long)ncol * nlay, n3 = n2 * m->ng;
-  double *layer_vmr = (double *)malloc(sizeof(double) * n2);
-  double *od = (double *)malloc(sizeof(double) * n3);
+  double *layer_vmr = (double *)tmp_alloc(sizeof(double) * n2);
+  double *od = (double *)tmp_alloc(sizeof(double) * n3);
   if (errmsg) errmsg[0] = 0;
   for (long q = 0; q < n3; ++q) tau[q] = 0.; /* :346 */
   int first_calc = 1;
@@ -192,8 +215,8 @@ int oracle_gas_optical_depth(const oracle_model_t *m, int ncol, int nlay, const 
     for (long q = 0; q < n3; ++q) tau[q] = tau[q] + od[q];       /* :370 */
     if (m->gas[i].composite_only) first_calc = 0;                /* :371-373 */
   }
-  free(layer_vmr);
-  free(od);
+  tmp_free(layer_vmr);
+  tmp_free(od);
   return 0;
 }
 
@@ -212,7 +235,7 @@ int oracle_gas_optics_int(const oracle_model_t *m, int ncol, int nlay, const dou
     return 1;
   }
   const long n2 = (long)ncol * (nlay + 1);
-  double *buffer = (double *)malloc(sizeof(double) * n2 * ng);
+  double *buffer = (double *)tmp_alloc(sizeof(double) * n2 * ng);
   oracle_calculate_planck_function(m, ncol, nlay + 1, tlev, buffer);       /* :419-422 */
   for (int k = 0; k < ng; ++k)
     for (int l = 0; l < nlay; ++l)
@@ -221,7 +244,7 @@ int oracle_gas_optics_int(const oracle_model_t *m, int ncol, int nlay, const dou
         lev_source_inc[o] = buffer[c + (long)ncol * ((l + 1) + (long)(nlay + 1) * k)]; /* :423 */
         lev_source_dec[o] = buffer[c + (long)ncol * (l + (long)(nlay + 1) * k)];       /* :424 */
       }
-  free(buffer);
+  tmp_free(buffer);
   return 0;
 }
 
@@ -231,16 +254,16 @@ int oracle_gas_optics_ext(const oracle_model_t *m, int ncol, int nlay, const dou
                           double *ssa, double *g, double *toa_src, char *errmsg) {
   const long n3 = (long)ncol * nlay * m->ng;
   oracle_gas_optical_depth(m, ncol, nlay, plev, tlay, gc, tau, errmsg);   /* :449 */
-  double *od = (double *)malloc(sizeof(double) * n3);
+  double *od = (double *)tmp_alloc(sizeof(double) * n3);
   oracle_calculate_rayleigh_optical_depth(m, ncol, nlay, plev, od);        /* :455 */
   for (long q = 0; q < n3; ++q) tau[q] = tau[q] + od[q];                   /* :456 */
   if (!ssa || !g) {                                                        /* :461-463 */
     if (errmsg) strcpy(errmsg, "shortwave must use ty_optical_props_2str");
-    free(od);
+    tmp_free(od);
     return 1;
   }
   for (long q = 0; q < n3; ++q) { ssa[q] = od[q] / tau[q]; g[q] = 0; }     /* :459-460 */
-  free(od);
+  tmp_free(od);
   for (int j = 0; j < m->ng; ++j)                                          /* :468-472 */
     for (int i = 0; i < ncol; ++i) toa_src[i + (long)ncol * j] = m->solar_irradiance[j];
   return 0;
@@ -370,9 +393,9 @@ void oracle_rte_lw_gpt(int ncol, int nlay, int ng, int top_at_1, int nmus, const
                        const oracle_solver_options_t *opt, double *flux_up, double *flux_dn,
                        double *gpt_flux_up, double *gpt_flux_dn) {
   const long n2 = (long)ncol * nlay, n2l = (long)ncol * (nlay + 1);
-  double *gup = (double *)malloc(sizeof(double) * n2l), *gdn = (double *)malloc(sizeof(double) * n2l);
-  double *rup = (double *)malloc(sizeof(double) * n2l), *rdn = (double *)malloc(sizeof(double) * n2l);
-  double *w1 = (double *)malloc(sizeof(double) * n2 * 4);
+  double *gup = (double *)tmp_alloc(sizeof(double) * n2l), *gdn = (double *)tmp_alloc(sizeof(double) * n2l);
+  double *rup = (double *)tmp_alloc(sizeof(double) * n2l), *rdn = (double *)tmp_alloc(sizeof(double) * n2l);
+  double *w1 = (double *)tmp_alloc(sizeof(double) * n2 * 4);
   for (int k = 0; k < ng; ++k) {
     const long o3 = n2 * k, o2 = (long)ncol * k;
     lw_solver_noscat(ncol, nlay, top_at_1, gauss_Ds[nmus - 1][0], gauss_wts[nmus - 1][0], tau + o3,
@@ -393,7 +416,7 @@ void oracle_rte_lw_gpt(int ncol, int nlay, int ng, int top_at_1, int nmus, const
     if (k == 0) for (long q = 0; q < n2l; ++q) { flux_up[q] = gup[q]; flux_dn[q] = gdn[q]; }
     else for (long q = 0; q < n2l; ++q) { flux_up[q] = flux_up[q] + gup[q]; flux_dn[q] = flux_dn[q] + gdn[q]; }
   }
-  free(gup); free(gdn); free(rup); free(rdn); free(w1);
+  tmp_free(gup); tmp_free(gdn); tmp_free(rup); tmp_free(rdn); tmp_free(w1);
 }
 
 /* sw_two_stream + sw_source_2str + adding for one g-point, one column at a time. */
@@ -426,7 +449,7 @@ void oracle_rte_sw_gpt(int ncol, int nlay, int ng, int top_at_1, const double *t
                        double *gpt_flux_dn, double *gpt_flux_dir) {
   const double eps = 2.220446049250313e-16;
   const long n2l = (long)ncol * (nlay + 1);
-  double *Rdif = (double *)malloc(sizeof(double) * nlay * 9 + sizeof(double) * (nlay + 1) * 6);
+  double *Rdif = (double *)tmp_alloc(sizeof(double) * nlay * 9 + sizeof(double) * (nlay + 1) * 6);
   double *Tdif = Rdif + nlay, *Rdir = Tdif + nlay, *Tdir = Rdir + nlay, *Tnoscat = Tdir + nlay;
   double *src_up = Tnoscat + nlay, *src_dn = src_up + nlay, *denom = src_dn + nlay;
   double *spare = denom + nlay;
@@ -507,7 +530,7 @@ void oracle_rte_sw_gpt(int ncol, int nlay, int ng, int top_at_1, const double *t
       }
     }
   }
-  free(Rdif);
+  tmp_free(Rdif);
 }
 
 /* ---- block loop of example/rfmip-rad-irf/ecckd_rfmip_lw.F90:107-136 ---- */
@@ -518,13 +541,27 @@ int oracle_lw_pipeline(const oracle_model_t *m, int ncol, int nlay, int block, i
   const int ng = m->ng;
   const int nblocks = (ncol + block - 1) / block;
   int status = 0;
+  /* bytes of temporaries one block needs: the block's own arrays below, gas_optical_depth (layer_vmr, optical_depth),
+   * the level-source buffer of gas_optics_int, rte_lw's work arrays; with head room */
+  const size_t n2b = (size_t)block * nlay, n2lb = (size_t)block * (nlay + 1);
+  const size_t per_block = sizeof(double) * (n2b * ng * 4 + (size_t)block * ng * 2 + n2b * 2 + n2lb * 4 + block   /* buf */
+                                             + n2b + n2b * ng                                                   /* layer_vmr, od */
+                                             + n2lb * ng                                                        /* buffer */
+                                             + n2lb * 4 + n2b * 4) + 64 * 32;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nthreads)
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+  char *arena = (char *)malloc(per_block);
+  tl_arena = arena; tl_cap = arena ? per_block : 0;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
 #endif
   for (int b = 0; b < nblocks; ++b) {
+    tl_off = 0;
     const int c0 = b * block, nc = (c0 + block <= ncol) ? block : ncol - c0;
     const long n2 = (long)nc * nlay, n2l = (long)nc * (nlay + 1);
-    double *buf = (double *)malloc(sizeof(double) * (n2 * ng * 4 + (long)nc * ng * 2 + n2 * 2 + n2l * 4 + nc));
+    double *buf = (double *)tmp_alloc(sizeof(double) * (n2 * ng * 4 + (long)nc * ng * 2 + n2 * 2 + n2l * 4 + nc));
     double *tau = buf, *lay = tau + n2 * ng, *inc = lay + n2 * ng, *dec = inc + n2 * ng;
     double *sfc = dec + n2 * ng, *emis = sfc + (long)nc * ng;
     double *bplev = emis + (long)nc * ng, *btlev = bplev + n2l, *btlay = btlev + n2l;
@@ -554,7 +591,10 @@ int oracle_lw_pipeline(const oracle_model_t *m, int ncol, int nlay, int block, i
         flux_up[c0 + c + (long)ncol * l] = fu[c + (long)nc * l];
         flux_dn[c0 + c + (long)ncol * l] = fd[c + (long)nc * l];
       }
-    free(buf);
+    tmp_free(buf);
+  }
+  tl_arena = NULL; tl_cap = 0; tl_off = 0;
+  free(arena);
   }
   return status;
 }
