@@ -196,7 +196,7 @@ def get_arithmetic():
 
 
 SOLVER_OPTIONS = ("lw_tau_thresh", "lw_series_terms", "lw_inc_flux_isotropic", "sw_k_floor", "sw_dir_clamp", "lw_solver",
-                  "lw_split_seg", "gas_merge_scalars", "lw_tail_split", "sw_tail_split", "sw_solver")
+                  "lw_split_seg", "gas_merge_scalars", "lw_tail_split", "sw_tail_split", "sw_solver", "gas_slab_f32")
 
 
 def set_solver_option(name, value):

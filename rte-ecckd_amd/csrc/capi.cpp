@@ -83,19 +83,20 @@ struct ScratchPool {
   int leases = 0;             // calls between acquiring a block and having launched on it
 };
 ScratchPool g_scratch_pool[16];
+ScratchPool g_flag_pool[16];   // one small block per (device, stream): the counter of the gas-optics spread probe ("gas_slab_f32" = auto)
 
 struct ScratchLease {
-  int device = -1;
+  ScratchPool *pool = nullptr;
   ScratchLease() = default;
   ScratchLease(const ScratchLease &) = delete;
   ScratchLease &operator=(const ScratchLease &) = delete;
-  void take(int dev) {   // (pool.mu held by the caller)
-    if (device < 0) { device = dev; ++g_scratch_pool[dev].leases; }
+  void take(ScratchPool &p) {   // (p.mu held by the caller)
+    if (!pool) { pool = &p; ++p.leases; }
   }
   ~ScratchLease() {
-    if (device < 0) return;
-    std::lock_guard<std::mutex> lock(g_scratch_pool[device].mu);
-    --g_scratch_pool[device].leases;
+    if (!pool) return;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    --pool->leases;
   }
 };
 
@@ -106,10 +107,10 @@ bool stream_is_capturing(hipStream_t stream) {
 
 // Returns the scratch block of (device, stream) with at least `need` bytes in *out; `lease` keeps it safe from other
 // host threads until the caller has launched (it must outlive the launches of the call).
-int stream_scratch(int device, hipStream_t stream, size_t need, void **out, ScratchLease &lease) {
-  ScratchPool &pool = g_scratch_pool[device];
+int stream_scratch(int device, hipStream_t stream, size_t need, void **out, ScratchLease &lease, ScratchPool *pools = g_scratch_pool) {
+  ScratchPool &pool = pools[device];
   std::lock_guard<std::mutex> lock(pool.mu);
-  lease.take(device);
+  lease.take(pool);
   ScratchPool::Block &b = pool.live[stream];
   const bool capturing = stream_is_capturing(stream);
   if (b.captured && !capturing && !b.caller_owned) {   // the block belongs to a captured graph: eager calls move on
@@ -148,9 +149,9 @@ int stream_scratch(int device, hipStream_t stream, size_t need, void **out, Scra
 
 // Same block, for a use the call can do without (the tail split of rte_lw): nullptr instead of an error when the block
 // cannot be provided (caller-owned block too small, stream being captured, allocation refused).
-void *stream_scratch_optional(int device, hipStream_t stream, size_t need, ScratchLease &lease) {
+void *stream_scratch_optional(int device, hipStream_t stream, size_t need, ScratchLease &lease, ScratchPool *pools = g_scratch_pool) {
   {
-    ScratchPool &pool = g_scratch_pool[device];
+    ScratchPool &pool = pools[device];
     std::lock_guard<std::mutex> lock(pool.mu);
     const auto it = pool.live.find(stream);
     const bool capturing = stream_is_capturing(stream);
@@ -161,7 +162,7 @@ void *stream_scratch_optional(int device, hipStream_t stream, size_t need, Scrat
     }
   }
   void *p = nullptr;
-  if (stream_scratch(device, stream, need, &p, lease)) {
+  if (stream_scratch(device, stream, need, &p, lease, pools)) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -213,6 +214,9 @@ std::atomic<int> g_arith{0};
 #ifndef ECCKD_LW_DEFAULT_SOLVER
 #define ECCKD_LW_DEFAULT_SOLVER 0
 #endif
+#ifndef ECCKD_GAS_SLAB_F32_DEFAULT
+#define ECCKD_GAS_SLAB_F32_DEFAULT 2
+#endif
 // Version switches of the (un-pinned) RTE-RRTMGP solvers, ecckd_set_solver_option.  Process-wide, read once
 // per call; the defaults are the v1.5-era forms the oracle restates.
 struct SolverOptions {
@@ -228,6 +232,7 @@ struct SolverOptions {
   std::atomic<int> gas_merge_scalars{1};
   std::atomic<int> lw_tail_split{1};
   std::atomic<int> sw_tail_split{1};
+  std::atomic<int> gas_slab_f32{ECCKD_GAS_SLAB_F32_DEFAULT};   // fp64 gas optics over the float32 image of the tables in LDS
   std::atomic<int> sw_solver{0};   // 0 layer-systolic (kernels_rte_sw_sys.hip; up to 60 layers), 1 per-lane two-pass kernel
 };
 SolverOptions g_opt;
@@ -397,6 +402,11 @@ int gas_optical_depth_dev(const ecckd_model *m, int ncol, int nlay, const double
         if (planck_done) *planck_done = true;
       }
       fa.f32 = g_f32;
+      // fp64 over the float32 image of the tables in LDS ("gas_slab_f32": 0 never, 1 always, 2 where the probe finds the
+      // columns spread over many pressure rows); the probe's counter is a word that belongs to this stream
+      ScratchLease flag_lease;
+      fa.slab32 = (!g_f32 && !g_plan && m->f32_exact && fa.mode == 1) ? g_opt.gas_slab_f32.load() : 0;
+      if (fa.slab32 == 2) fa.choose_buf = static_cast<int *>(stream_scratch_optional(m->device, stream, 256, flag_lease, g_flag_pool));
       if (g_f32 && ((fa.mode != 1 && fa.mode != 2) || !last || !first_pass))
         return fail("ecckd: single precision is implemented for one-pass gas optics (fused longwave, shortwave); this "
                     "model / gas list needs the multi-pass or unfused path");
@@ -566,9 +576,13 @@ int ecckd_set_solver_option(const char *name, double value) {
     if (value != 0. && value != 1.) return fail("ecckd_set_solver_option: sw_solver must be 0 (layer-systolic) or 1 (two-pass per lane)");
     g_opt.sw_solver.store((int)value);
   }
+  else if (n == "gas_slab_f32") {
+    if (value != 0. && value != 1. && value != 2.) return fail("ecckd_set_solver_option: gas_slab_f32 must be 0 (never), 1 (always) or 2 (auto)");
+    g_opt.gas_slab_f32.store((int)value);
+  }
   else return fail("ecckd_set_solver_option: unknown option '" + n + "' (lw_tau_thresh, lw_series_terms, "
                    "lw_inc_flux_isotropic, sw_k_floor, sw_dir_clamp, lw_solver, lw_split_seg, gas_merge_scalars, lw_tail_split, "
-                   "sw_tail_split, sw_solver)");
+                   "sw_tail_split, sw_solver, gas_slab_f32)");
   return 0;
 }
 
@@ -586,6 +600,7 @@ int ecckd_get_solver_option(const char *name, double *value) {
   else if (n == "lw_tail_split") *value = g_opt.lw_tail_split.load();
   else if (n == "sw_tail_split") *value = g_opt.sw_tail_split.load();
   else if (n == "sw_solver") *value = g_opt.sw_solver.load();
+  else if (n == "gas_slab_f32") *value = g_opt.gas_slab_f32.load();
   else return fail("ecckd_get_solver_option: unknown option '" + n + "'");
   return 0;
 }
@@ -627,9 +642,13 @@ int ecckd_set_stream_scratch(int device, void *stream, void *buffer, size_t byte
   return 0;
 }
 
+static int release_pool(ScratchPool &pool, int device);
 int ecckd_release_scratch(int device) {
   if (device < 0 || device >= 16) return fail("ecckd_release_scratch: bad device ordinal");
-  ScratchPool &pool = g_scratch_pool[device];
+  if (release_pool(g_flag_pool[device], device)) return 1;
+  return release_pool(g_scratch_pool[device], device);
+}
+static int release_pool(ScratchPool &pool, int device) {
   std::lock_guard<std::mutex> lock(pool.mu);
   if (pool.live.empty() && pool.retired.empty()) return 0;
   HIPCHK(hipSetDevice(device));
@@ -804,6 +823,10 @@ int ecckd_model_finalize(ecckd_model_t *m, int device) {
   HIPCHK(hipMemcpy(m->dbuf, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
   {   // the same image rounded to float, for the single-precision entry points
     std::vector<float> hostf(host.begin(), host.end());
+    // ... and whether that rounding changed anything: ecCKD's files hold float32 variables (widened exactly by the reader,
+    // example/rfmip-rad-irf/mo_simple_netcdf.F90:44-142), so a fp64 kernel may stage them in LDS as float32 ("gas_slab_f32")
+    m->f32_exact = true;
+    for (size_t i = 0; i < host.size() && m->f32_exact; ++i) m->f32_exact = (double)hostf[i] == host[i];
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->dbuf32), hostf.size() * sizeof(float)));
     HIPCHK(hipMemcpy(m->dbuf32, hostf.data(), hostf.size() * sizeof(float), hipMemcpyHostToDevice));
   }

@@ -79,6 +79,12 @@ struct FusedArgs {
   UDiv ud_dlp, ud_dt, ud_dlv, ud_pdt;          // filled by launch_gas_fused
   SlotArgs slot[kTauPassGases + 1];            // filled by launch_gas_fused
   int f32;                     // 1: every data pointer addresses float arrays (LW fused path only)
+  int slab32;                  // fp64 call: stage the tables in LDS as the float32 they are (model checked: every value is
+                               // float32-representable): 1 always, 2 where the columns are spread over many pressure rows
+                               // (spread probe); prepare_gas_fused clears it where no such instantiation exists
+  int *choose_buf;             // slab32 == 2: one int of device memory owned by the call's stream (the probe's counter), or null
+  const int *choose;           // (set by launch_gas_fused) the probe's counter, or null: unconditional launch
+  int choose_total;            // (set by launch_gas_fused) waves of 64 columns in the call
   int mode;                    // 0 tau only, 1 longwave (tau + Planck sources), 2 shortwave epilogue
   int ntp;
   int pw;                      // Planck rows staged in LDS (ntp, or a window); filled by launch_gas_fused

@@ -108,11 +108,13 @@ struct FLayout {
 //       zero-weight slots read finite data).
 // ngp = g-points per row in LDS: ng rounded up to the chunk size GC (the tail stays zero).
 // ntp = Planck rows held in LDS (the whole table, or the window FusedArgs::pw).
-__host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp) {
+// Offsets are in elements of the LDS storage type; `wide` = sizeof(arithmetic type) / sizeof(storage type) (2 for the
+// fp32 image of an fp64 call): the reduction scratch holds arithmetic-type values.
+__host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp, int wide = 1) {
   FLayout L;
   L.tb = 0;
   L.red = (np + 1) & ~1;
-  L.bil = L.red + 4 * kWaves;
+  L.bil = L.red + 4 * kWaves * wide;
   L.SB = nbil > 0 ? row_stride(nbil * ngp) : 2;
   L.lut = L.bil + R * nt * L.SB + NB * ngp;
   L.SL = nv_lut > 0 ? row_stride(ngp) : 2;
@@ -136,18 +138,51 @@ template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(
 
 enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
 
-template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+// "gas_slab_f32" = auto.  The fp64 slab holds R = 3 pressure rows next to the Planck table, the float32 image R = 8; the
+// widening costs 9 % where 3 rows do (measured, round 3: 13.6 against 12.6 ms at 1e6 columns) and saves a factor 3.4
+// where the columns of a wave are spread over more rows than a slab position serves (surface pressures of 50-103 kPa
+// shuffled over the columns: 11.1 -> 3.3 ms at 2e5 columns).  spread_probe_kernel counts, at the bottom layer of the
+// call (where the spread is largest), the waves of 64 columns whose pressure indices span three values or more; more than
+// one wave in kSpreadOneIn -> the float32 image.  Both forms give the same bits, so the choice only moves time.
+constexpr int kSpreadOneIn = 24;
+template <typename real>
+__global__ void __launch_bounds__(256) spread_probe_kernel(const real *plev, int ncol, int nlay, real lp0, UDiv dlp_h, int np, int *count) {
+  // both ends of the arrays (blockIdx.y): the call does not say which one is the surface, and the top contributes nothing
+  const real *plev0 = plev + (long)ncol * (blockIdx.y ? nlay - 1 : 0), *plev1 = plev0 + ncol;
+  const UDivT<real> dlp = make_udiv_t<real>(dlp_h);
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  int ip = -1;
+  if (c < ncol) ip = pressure_point<real>(plev0[c], plev1[c], lp0, dlp, np).ip0;
+  int lo = ip < 0 ? 0x7fffffff : ip, hi = ip;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0 && hi - lo >= 2) atomicAdd(count, 1);
+}
+
+// sreal: type of the tables in LDS.  = real, or float under a double kernel: every table of the ecCKD files is float32 on
+// disk (widened exactly on read, mo_simple_netcdf.F90:44-142), so the slab and the Planck table can be staged as the
+// float32 they are -- half the LDS -- and widened again (v_cvt_f64_f32, exact) when they are used: the same bits.  The
+// host checks that every value is float32-representable (FusedArgs::slab32).
+template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
 __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  real *lds = reinterpret_cast<real *>(lds_raw);
-  typedef real double2_t __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) const volatile real lds_cvd;
+  sreal *lds = reinterpret_cast<sreal *>(lds_raw);
+  typedef sreal double2_t __attribute__((ext_vector_type(2)));   // (two consecutive g-points as they sit in LDS)
+  typedef __attribute__((address_space(3))) const volatile sreal lds_cvd;
   typedef __attribute__((address_space(3))) const volatile double2_t lds_cvd2;
   lds_cvd *lv = (lds_cvd *)lds;
-  // two consecutive g-points in one ds_read_b128
+  // two consecutive g-points in one ds_read_b128 (ds_read_b64 for a float32 image)
   // (at a BYTE address plus a compile-time element offset, the immediate of the ds_read)
   typedef __attribute__((address_space(3))) const volatile char lds_cvc;
-  auto ld2b = [&](int bytes, int elem) -> double2_t { return *(lds_cvd2 *)((lds_cvc *)lv + bytes + elem * (int)sizeof(real)); };
+  auto ld2b = [&](int bytes, int elem) -> double2_t { return *(lds_cvd2 *)((lds_cvc *)lv + bytes + elem * (int)sizeof(sreal)); };
+  constexpr int WIDE = (int)(sizeof(real) / sizeof(sreal));
+  if (a.choose) {   // "gas_slab_f32" = auto: both forms are launched, the spread probe's count says which one works
+    const bool want32 = (long)a.choose[0] * kSpreadOneIn > (long)a.choose_total;
+    if (want32 != (WIDE == 2)) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wcol = (tid & ~63) + wave_column(lane);   // column of this thread inside a tile
   const int j = blockIdx.y;
@@ -157,8 +192,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   const int ntp = MODE == MODE_LW ? a.ntp : 0;
   const int PW = MODE == MODE_LW ? a.pw : 0;   // Planck rows staged in LDS: ntp (whole table) or a window
   const int ngp = (ng + GC - 1) / GC * GC;
-  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, PW);
-  real *redd = lds + L.red;
+  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, PW, WIDE);
+  real *redd = reinterpret_cast<real *>(lds + L.red);
   // The argument structs carry `double` pointers and scalars; in the single-precision
   // instantiation the pointers address float data (host side casts) and the scalars are rounded.
   auto P = [](const double *p) { return reinterpret_cast<const real *>(p); };
@@ -169,9 +204,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 
   // Everything a zero-weight slot (unused bilinear slot, absent look_up_table gas) can read must
   // be finite: clear the whole allocation once, the staged rows overwrite their part.
-  for (int i = tid; i < L.total; i += kBlock) lds[i] = real(0);
+  for (int i = tid; i < L.total; i += kBlock) lds[i] = sreal(0);
   __syncthreads();
-  for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = P(t.temperature)[i];
+  for (int i = tid; i < np; i += kBlock) lds[L.tb + i] = (sreal)P(t.temperature)[i];
   int pw_lo = -1;   // first table row of the staged Planck window (-1: nothing staged yet)
   // per-column inputs: wave-uniform row pointers (this block's layer) + 32-bit per-lane byte offsets
   typedef __attribute__((address_space(1))) const char gcchar_t;
@@ -256,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         pw_lo = want;
         for (int q = tid; q < PW * ng; q += kBlock) {
           const int r = q / ng, g = q - r * ng;
-          lds[L.pl + r * L.SP + g] = P(a.planck)[(long)(pw_lo + r) * ng + g];
+          lds[L.pl + r * L.SP + g] = (sreal)P(a.planck)[(long)(pw_lo + r) * ng + g];
         }
       }
     }
@@ -283,13 +318,14 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         const long row = (long)ng * ((slab_lo + ipl) + (long)np * it);
         // a row holds [g-point chunk][slot][GC g-points]: inside a chunk every (slot, g-point) is a compile-time
         // offset from the four corner addresses of the cell
-        real *dst = lds + L.bil + rb * L.SB + s * GC;
+        sreal *dst = lds + L.bil + rb * L.SB + s * GC;
         const int cs = t.nbil * GC;
         if (s == t.merge_slot) {   // sum_k mult_k * coefficient_k: the call-constant gases as one table
-          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = merged_coef(row + g);
+          // (never with a float32 image under a double kernel: the sums are not float32 numbers -- the host keeps the two apart)
+          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = (sreal)merged_coef(row + g);
         } else {
           const real *src = P(t.seq[t.bil_seq[s]].coef) + row;
-          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = src[g];
+          for (int g = lane; g < ng; g += 64) dst[(g / GC) * cs + g % GC] = (sreal)src[g];
         }
       }
       if (t.lut >= 0) {
@@ -298,8 +334,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         for (int q = wave; q < rows_l; q += kWaves) {
           const int ipl = q % R, itv = q / R;
           const real *src = coef + (long)ng * ((slab_lo + ipl) + (long)np * itv);
-          real *dst = lds + L.lut + q * L.SL;
-          for (int g = lane; g < ng; g += 64) dst[g] = src[g];
+          sreal *dst = lds + L.lut + q * L.SL;
+          for (int g = lane; g < ng; g += 64) dst[g] = (sreal)src[g];
         }
       }
     };
@@ -377,7 +413,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
       const bool inslab = (R >= 2) && slab_lo >= 0 && ipl >= 0 && ipl + 1 <= R - 1;
       ipl = ipl < 0 ? 0 : (ipl > R - 2 ? (R >= 2 ? R - 2 : 0) : ipl);
 
-      const real t0 = pp.pw0 * lds[L.tb + ip0 - 1] + pp.pw1 * lds[L.tb + ip0];   // :131-132
+      const real t0 = pp.pw0 * (real)lds[L.tb + ip0 - 1] + pp.pw1 * (real)lds[L.tb + ip0];   // :131-132
       real temperature_index = udiv(Tlayer - t0, ud_dt);
       temperature_index = real(1) + selmax(real(0), selmin(temperature_index, (real)nt - real(1.0001)));
       const int it0 = (int)temperature_index;
@@ -461,7 +497,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
         const int ol = t.lut >= 0 ? L.lut + (ipl + R * ((it0 - 1) + nt * (iv0 - 1))) * L.SL : L.bil;
         const int dPb = L.SB, dTb = R * L.SB;
         const int dPl = t.lut >= 0 ? L.SL : 0, dTl = t.lut >= 0 ? R * L.SL : 0, dVl = t.lut >= 0 ? R * nt * L.SL : 0;
-        constexpr int ES = (int)sizeof(real);   // (the registers hold byte addresses)
+        constexpr int ES = (int)sizeof(sreal);   // (the registers hold byte addresses)
         int ab[4] = {ES * ob, ES * (ob + dPb), ES * (ob + dTb), ES * (ob + dTb + dPb)};
         int al[8] = {ES * ol, ES * (ol + dPl), ES * (ol + dTl), ES * (ol + dTl + dPl),
                      ES * (ol + dVl), ES * (ol + dVl + dPl), ES * (ol + dVl + dTl), ES * (ol + dVl + dTl + dPl)};
@@ -554,8 +590,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                 if ((pi_ & 1) == 0) {
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
-                    real v = l000 * b[0][q];
-                    v = fma(l100, b[1][q], v); v = fma(l010, b[2][q], v); v = fma(l110, b[3][q], v);
+                    real v = l000 * (real)b[0][q];
+                    v = fma(l100, (real)b[1][q], v); v = fma(l010, (real)b[2][q], v); v = fma(l110, (real)b[3][q], v);
                     asm volatile("" : "+v"(v));
                     lutp[q] = v;
                   }
@@ -563,8 +599,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
                     real v = lutp[q];
-                    v = fma(l001, b[0][q], v); v = fma(l101, b[1][q], v); v = fma(l011, b[2][q], v);
-                    v = fma(l111, b[3][q], v);
+                    v = fma(l001, (real)b[0][q], v); v = fma(l101, (real)b[1][q], v); v = fma(l011, (real)b[2][q], v);
+                    v = fma(l111, (real)b[3][q], v);
                     if (ANYCLAMP) { v = vlut * v; v = v < real(0) ? real(0) : v; }
                     acc[g0 + q] = acc[g0 + q] + v;
                     asm volatile("" : "+v"(acc[g0 + q]));
@@ -574,8 +610,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                 constexpr int s = bil_slot(pi_ - NLI, NB, NP2), g0 = 2 * bil_pair(pi_ - NLI, NB, NP2);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                  real v = a00 * b[0][q];
-                  v = fma(a10, b[1][q], v); v = fma(a01, b[2][q], v); v = fma(a11, b[3][q], v);
+                  real v = a00 * (real)b[0][q];
+                  v = fma(a10, (real)b[1][q], v); v = fma(a01, (real)b[2][q], v); v = fma(a11, (real)b[3][q], v);
                   if (ANYCLAMP) { v = W[s] * v; v = v < real(0) ? real(0) : v; acc[g0 + q] = acc[g0 + q] + v; }
                   else acc[g0 + q] = fma(W[s], v, acc[g0 + q]);
                   asm volatile("" : "+v"(acc[g0 + q]));
@@ -620,8 +656,8 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                   real vl[2], v1[2];
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
-                    vl[q] = div_pi(qlay.w0 * b[0][q] + qlay.w1 * b[1][q], pi, rpi);
-                    v1[q] = div_pi(ql1.w0 * b[2][q] + ql1.w1 * b[3][q], pi, rpi);
+                    vl[q] = div_pi(qlay.w0 * (real)b[0][q] + qlay.w1 * (real)b[1][q], pi, rpi);
+                    v1[q] = div_pi(ql1.w0 * (real)b[2][q] + ql1.w1 * (real)b[3][q], pi, rpi);
                   }
                   if (both) {
                     store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], masked, active);
@@ -639,7 +675,7 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
                 } else {
                   real v0[2];
 #pragma unroll
-                  for (int q = 0; q < 2; ++q) v0[q] = div_pi(ql0.w0 * b[0][q] + ql0.w1 * b[1][q], pi, rpi);
+                  for (int q = 0; q < 2; ++q) v0[q] = div_pi(ql0.w0 * (real)b[0][q] + ql0.w1 * (real)b[1][q], pi, rpi);
                   if (a.tlev) {
                     if (both) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], masked, active);
                     else if (gb + g < ng && active) Q(a.lev_source_dec)[o1] = v0[0];
@@ -742,9 +778,9 @@ __global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
   }
 }
 
-template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE>
+template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
 hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
-  auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE>;
+  auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE, sreal>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -780,6 +816,11 @@ hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp,
 // serve tables whose g-point count is not a multiple of 4, e.g. the 27 g-points of the shortwave table with
 // more than 7 gases.)
 // (GC, NB) of the instantiation launch_mode() will pick
+// float32 image of the tables under a double kernel: instantiated for the full-chunk longwave shape of the ecCKD files
+bool slab32_applies(int mode, int ng, int nbil, bool anyclamp) {
+  return mode == MODE_LW && !anyclamp && ng % 8 == 0 && pick_nb(nbil) == 7;
+}
+
 void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
   const int nb = pick_nb(nbil);
   if (anyclamp) { *GC = 4; *NB = kTauPassGases; }
@@ -790,20 +831,35 @@ void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
   else { *GC = 4; *NB = kTauPassGases; }
 }
 
+// LDS a block may take: all of a CU's (one block per CU), or ECCKD_FUSED_LDS_KB for experiments with several blocks per CU
+size_t lds_budget() {
+#ifdef ECCKD_FUSED_LDS_KB
+  return (size_t)ECCKD_FUSED_LDS_KB * 1024;
+#else
+  return (size_t)kLdsBudget;
+#endif
+}
+
 }  // namespace
 
 // Rows of the LDS slab for a fused launch that keeps `pl_rows` rows of the Planck table in LDS, or 0
 // if it does not fit with at least `min_rows`.
+// f32: 0 double arithmetic and tables, 1 float arithmetic and tables, 2 double arithmetic over the float32 image of the
+// tables (FusedArgs::slab32).
 int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32) {
   int GC, NB;
   pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
   const int ngp = (ng + GC - 1) / GC * GC;
   const size_t esz = f32 ? sizeof(float) : sizeof(double);
+  const size_t budget = lds_budget();
   int R = 0;
   for (int r = 2; r <= np; ++r) {
-    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows).total <= (size_t)kLdsBudget) R = r;
+    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows, f32 == 2 ? 2 : 1).total <= budget) R = r;
     else break;
   }
+#ifdef ECCKD_FUSED_MAXROWS   // (experiments: cap the slab)
+  if (R > ECCKD_FUSED_MAXROWS) R = ECCKD_FUSED_MAXROWS;
+#endif
   return R >= min_rows ? R : 0;
 }
 
@@ -932,9 +988,14 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   int GC, NB;
   pick_shape(t.ng, t.nbil, anyclamp, &GC, &NB);
   const int ngp = (t.ng + GC - 1) / GC * GC;
-  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, a.f32);
-  const size_t lds = (a.f32 ? sizeof(float) : sizeof(double)) * (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw).total;
-  if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+  // float32 image of the tables under a double kernel: only the instantiations built for it (slab32_applies)
+  if (a.slab32 && !(a.f32 == 0 && slab32_applies(a.mode, t.ng, t.nbil, anyclamp) && t.merge_slot < 0)) a.slab32 = 0;
+  const int store = a.f32 ? 1 : (a.slab32 ? 2 : 0);
+  if (a.mode == MODE_LW && store == 2) a.pw = fused_planck_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.ntp, anyclamp, 2);
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, store);
+  const size_t lds = (store ? sizeof(float) : sizeof(double)) *
+                     (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw, store == 2 ? 2 : 1).total;
+  if (lds > lds_budget()) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full
   const long ntiles = ((long)t.ncol + kBlock - 1) / kBlock;
@@ -958,10 +1019,36 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
 
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s) {
   FusedPlan plan;
+  if (a.slab32 == 2) {   // auto: spread probe, then both forms; the one the probe does not choose returns at once
+    FusedArgs b = a;
+    b.slab32 = 1;
+    FusedPlan pb;
+    hipError_t eb = prepare_gas_fused(b, pb);
+    if (eb == hipSuccess && !pb.empty && b.slab32 == 1 && a.choose_buf) {
+      a.slab32 = 0;
+      eb = prepare_gas_fused(a, plan);
+      if (eb != hipSuccess) return eb;
+      const TauArgs &t = a.tau;
+      eb = hipMemsetAsync(a.choose_buf, 0, sizeof(int), s);
+      if (eb != hipSuccess) return eb;
+      const long nw = ((long)t.ncol + 63) / 64;
+      hipLaunchKernelGGL(spread_probe_kernel<double>, dim3((unsigned)((t.ncol + 255) / 256), t.nlay > 1 ? 2 : 1), dim3(256), 0, s,
+                         t.plev, t.ncol, t.nlay, t.lp0, a.ud_dlp, t.np, a.choose_buf);
+      eb = hipGetLastError();
+      if (eb != hipSuccess) return eb;
+      a.choose = b.choose = a.choose_buf;
+      a.choose_total = b.choose_total = (int)(nw > 0x7fffffff ? 0x7fffffff : nw);
+      eb = launch_mode<double, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), plan.anyclamp != 0, s);
+      if (eb != hipSuccess) return eb;
+      return launch_one<double, 8, 7, true, false, MODE_LW, float>(b, pb.lds_bytes, s);
+    }
+    a.slab32 = 0;   // no float32 form for this shape (or no room for the probe's counter): the fp64 slab
+  }
   const hipError_t e = prepare_gas_fused(a, plan);
   if (e != hipSuccess || plan.empty) return e;
   const TauArgs &t = a.tau;
   const bool anyclamp = plan.anyclamp != 0;
+  if (a.slab32 && !a.f32) return launch_one<double, 8, 7, true, false, MODE_LW, float>(a, plan.lds_bytes, s);
   if (a.f32 && a.mode == MODE_SW) return launch_mode<float, MODE_SW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
   if (a.f32) return launch_mode<float, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);
   if (a.mode == MODE_LW) return launch_mode<double, MODE_LW>(a, plan.lds_bytes, pick_nb(t.nbil), anyclamp, s);

@@ -35,6 +35,7 @@ struct ecckd_model {
   int device = -1;
   double *dbuf = nullptr;               // all tables, one allocation
   float *dbuf32 = nullptr;              // the same image in single precision (same offsets)
+  bool f32_exact = false;               // every table value is a float32 number (true for files read from float32 variables)
   size_t off_temperature = 0, off_planck = 0, off_rayleigh = 0, off_solar = 0;
   size_t off_zero = 0;                  // 32 zero words: target of the loads of unused gas slots
   // --- ECCKD_HOST staging arena (grown on demand, serialised by mu) ---

@@ -7,7 +7,8 @@
 ! device_resident = 1: optical_props / source are the device twins of mo_ecckd_device (tau and the sources stay in
 ! HBM between gas_optics and the solver; ECCKD_MIXED memory space of the C ABI).
 ! repeats: the block loop is run that many times and the best wall time is printed ("loop_seconds", bench.py reads it).
-! fused = 1 (lw): one call ecckd%lw_fluxes(...) per block instead of gas_optics + rte_lw (the library's fused longwave path).
+! fused = 1: one call ecckd%lw_fluxes(...) / ecckd%sw_fluxes(...) per block instead of gas_optics + rte_lw / rte_sw (the library's
+!            fused paths).
 ! byband = 1: fluxes go through ty_fluxes_byband (per-band arrays; their sum over bands must reproduce the broadband
 ! fluxes, which are what output.bin holds either way).
 !
@@ -189,8 +190,18 @@ program ecckd_driver
       ! ecckd level sources hold one value per level (src/gas_optics_ecckd.f90:419-424): each level is read once
       call stop_on_err(rte_lw(op1, top_at_1, source, sfc_spec, fluxes, n_gauss_angles=n_quad_angles, &
                               lev_sources_shared=.true.))
+    else if (fused /= 0) then
+      if (allocated(sfc_spec2)) deallocate(sfc_spec2)
+      allocate(sfc_spec2(nbnd, nc))
+      do i = 1, nc
+        sfc_spec(:, i) = bc2(c0 + i - 1)                     ! albedo, direct = diffuse (ecckd_rfmip_sw.F90:136-141)
+        sfc_spec2(:, i) = bc2(c0 + i - 1)
+      end do
+      call stop_on_err(ecckd%sw_fluxes(plev(c0:c1, :), tlay(c0:c1, :), gas_concs(b), top_at_1, bc1(c0:c1), sfc_spec, sfc_spec2, &
+                                       flux_up(c0:c1, :), flux_dn(c0:c1, :)))
     else
-      if (allocated(sfc_spec2)) deallocate(sfc_spec2, toa)
+      if (allocated(sfc_spec2)) deallocate(sfc_spec2)
+      if (allocated(toa)) deallocate(toa)
       allocate(sfc_spec2(nbnd, nc), toa(nc, ecckd%get_ngpt()))
       do i = 1, nc
         sfc_spec(:, i) = bc2(c0 + i - 1)                     ! albedo, direct = diffuse (ecckd_rfmip_sw.F90:136-141)

@@ -53,6 +53,7 @@ module gas_optics_ecckd
     procedure, public :: gas_optics_int
     procedure, public :: gas_optics_ext
     procedure, public :: lw_fluxes          !< extension: gas_optics + rte_lw in one call (fused longwave path)
+    procedure, public :: sw_fluxes          !< extension: gas_optics + rte_sw in one call (fused shortwave path)
   end type ty_gas_optics_ecckd
 
   interface
@@ -181,6 +182,22 @@ module gas_optics_ecckd
       type(c_ptr), value :: stream
       integer(c_int) :: rc
     end function c_lw_fluxes
+    function c_sw_fluxes(model, ncol, nlay, plev, tlay, ngas, gas_names, vmr, cs, ls, scalar, top_at_1, mu0, toa_scale, &
+                         sfc_alb_dir, sfc_alb_dif, flux_up, flux_dn, flux_dir, memspace, stream) &
+        bind(C, name="ecckd_sw_fluxes") result(rc)
+      import c_ptr, c_int, c_double, c_char, c_long_long
+      type(c_ptr), value :: model
+      integer(c_int), value :: ncol, nlay, ngas, top_at_1, memspace
+      real(c_double), dimension(*), intent(in) :: plev, tlay, mu0, sfc_alb_dir, sfc_alb_dif
+      character(kind=c_char), dimension(*), intent(in) :: gas_names
+      type(c_ptr), dimension(*), intent(in) :: vmr
+      integer(c_long_long), dimension(*), intent(in) :: cs, ls
+      real(c_double), dimension(*), intent(in) :: scalar
+      type(c_ptr), value :: toa_scale, flux_dir
+      real(c_double), dimension(*), intent(inout) :: flux_up, flux_dn
+      type(c_ptr), value :: stream
+      integer(c_int) :: rc
+    end function c_sw_fluxes
   end interface
 
   public :: c_error_message, c_loc_3d, c_loc_2d
@@ -529,6 +546,67 @@ contains
     flux_up = up
     flux_dn = dn
   end function lw_fluxes
+
+  !> Extension (no counterpart in the reference): broadband shortwave fluxes in one call -- what the reference's block
+  !! loop computes with ecckd%gas_optics(...), the rescaling of toa_flux and rte_sw(...) (ecckd_rfmip_sw.F90:118-154) --
+  !! through the fused path of the library (ecckd_sw_fluxes: only the total optical depth goes through GPU memory; the
+  !! solver derives ssa, g = 0 and the incoming beam as gas_optics_ext does, src/gas_optics_ecckd.f90:455-472).  Host
+  !! arrays in, host fluxes out; at most 60 layers.  flux_* are (ncol, nlay+1), the albedos (nband, ncol); toa_scale(ncol)
+  !! multiplies the incoming beam of a column (the drivers' total-solar-irradiance rescaling); flux_dir is optional.
+  function sw_fluxes(this, plev, tlay, gas_desc, top_at_1, mu0, sfc_alb_dir, sfc_alb_dif, flux_up, flux_dn, flux_dir, toa_scale) &
+      result(error_msg)
+    class(ty_gas_optics_ecckd), intent(in) :: this
+    real(wp), dimension(:,:), intent(in) :: plev, tlay
+    type(ty_gas_concs), intent(in) :: gas_desc
+    logical, intent(in) :: top_at_1
+    real(wp), dimension(:), intent(in) :: mu0
+    real(wp), dimension(:,:), intent(in) :: sfc_alb_dir, sfc_alb_dif
+    real(wp), dimension(:,:), intent(inout) :: flux_up, flux_dn
+    real(wp), dimension(:,:), intent(inout), optional :: flux_dir
+    real(wp), dimension(:), intent(in), optional, target :: toa_scale
+    character(len=128) :: error_msg
+    character(kind=c_char), dimension(:), allocatable :: names
+    type(c_ptr), dimension(:), allocatable :: ptr
+    integer(c_long_long), dimension(:), allocatable :: cs, ls
+    real(c_double), dimension(:), allocatable :: scalar
+    real(wp), dimension(:,:), allocatable, target :: up, dn, dir
+    real(wp), dimension(:), allocatable, target :: scale
+    type(c_ptr) :: scale_p, dir_p
+    integer :: ncol, nlay, n
+    integer(c_int) :: rc
+    ncol = size(tlay, 1)
+    nlay = size(tlay, 2)
+    error_msg = marshal_gases(this, gas_desc, ncol, nlay, names, ptr, cs, ls, scalar)
+    if (trim(error_msg) /= "") return
+    if (size(sfc_alb_dir, 1) /= this%get_nband() .or. size(sfc_alb_dir, 2) /= ncol .or. &
+        size(sfc_alb_dif, 1) /= this%get_nband() .or. size(sfc_alb_dif, 2) /= ncol) then
+      error_msg = "sw_fluxes: surface albedos inconsistently sized"
+      return
+    end if
+    n = gas_desc%get_num_gases()
+    allocate(up(ncol, nlay + 1), dn(ncol, nlay + 1))
+    scale_p = c_null_ptr
+    dir_p = c_null_ptr
+    if (present(toa_scale)) then
+      allocate(scale(ncol))
+      scale = toa_scale
+      scale_p = c_loc(scale(1))
+    end if
+    if (present(flux_dir)) then
+      allocate(dir(ncol, nlay + 1))
+      dir_p = c_loc(dir(1, 1))
+    end if
+    rc = c_sw_fluxes(this%handle, int(ncol, c_int), int(nlay, c_int), plev, tlay, int(n, c_int), names, ptr, cs, ls, scalar, &
+                     merge(1_c_int, 0_c_int, top_at_1), mu0, scale_p, sfc_alb_dir, sfc_alb_dif, up, dn, dir_p, ECCKD_HOST, &
+                     c_null_ptr)
+    if (rc /= 0) then
+      error_msg = c_error_message()
+      return
+    end if
+    flux_up = up
+    flux_dn = dn
+    if (present(flux_dir)) flux_dir = dir
+  end function sw_fluxes
 
   function c_loc_3d(a) result(p)
     real(wp), dimension(:,:,:), intent(in), target, contiguous :: a

@@ -293,7 +293,12 @@ def test_code_object_resources(pkg):
         if kind == "rte_lw_split_kernel" and targs[5] == "true":      # Planck-recomputing form: two waves per SIMD, no spill
             assert targs[0] == "15" and targs[6] == "2" and k["spill_vgpr"] == 0, name
     assert seen == {"gas_fused_kernel", "rte_lw_kernel", "rte_lw_split_kernel", "rte_sw_kernel", "tau_kernel"}
-    head = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1>" in n]
+    # the headline instantiation, over the fp64 slab and over the float32 image of the tables ("gas_slab_f32")
+    head = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, double>" in n]
     assert len(head) == 1 and head[0]["vgpr"] <= 256 and kernel_resources.waves_per_simd(head[0]) == 2
+    head32 = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, float>" in n]
+    assert len(head32) == 1 and head32[0]["spill_vgpr"] == 0 and kernel_resources.waves_per_simd(head32[0]) == 2
+    sys_sw = [k for n, k in ks.items() if "rte_sw_sys_kernel<double, true, false, false, true>" in n]
+    assert len(sys_sw) == 1 and kernel_resources.waves_per_simd(sys_sw[0]) == 3     # 12 waves per block, one block per CU
     sw = [k for n, k in ks.items() if "rte_sw_kernel<16, true, true, false>" in n]
     assert len(sw) == 1 and kernel_resources.waves_per_simd(sw[0]) == 3       # 143 VGPRs: 12 waves per CU

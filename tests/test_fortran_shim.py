@@ -190,6 +190,30 @@ def test_fortran_fused_lw_fluxes(pkg, gpu, oracle_mod, tmp_path):
     assert np.max(np.abs(out["1"][0] - ofu)) < FLUX_ATOL and np.max(np.abs(out["1"][1] - ofd)) < FLUX_ATOL
 
 
+@pytest.mark.gpu
+def test_fortran_fused_sw_fluxes(pkg, gpu, oracle_mod, tmp_path):
+    """ecckd%sw_fluxes (type-bound extension over ecckd_sw_fluxes: the fused shortwave path) gives the fluxes of
+    ecckd%gas_optics + rte_sw bit for bit, block by block, and the oracle's to the fp64 bar."""
+    drv = pkg.FORTRAN_DRIVER if os.path.exists(pkg.FORTRAN_DRIVER) else pkg.build_fortran()
+    if drv is None:
+        pytest.skip("no Fortran driver binary and no amdflang")
+    ms = oracle_mod.CkdModel(SW_WIDE)
+    ncol = 250
+    cols = synthetic.columns(5, ncol, float(np.exp(ms.log_pressure[0])), shortwave=True)
+    write_input(tmp_path / "insw.bin", cols, synthetic.GAS_ORDER, True)
+    out = {}
+    for fused in ("0", "1"):
+        r = subprocess.run([drv, "sw", SW_WIDE, str(tmp_path / "insw.bin"), str(tmp_path / ("o%s.bin" % fused)), "100", "1", "0", "1", "0", fused],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out[fused] = read_output(tmp_path / ("o%s.bin" % fused), ncol, 60)
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    tau, ssa, g, toa, _ = oracle_mod.gas_optics_ext(ms, cols["plev"], cols["tlay"], helpers.oracle_gas_items(cols, synthetic.GAS_ORDER))
+    alb = np.repeat(cols["albedo"][None], 27, 0)
+    ofu, ofd, _ = oracle_mod.rte_sw(tau, ssa, g, cols["mu0"], toa, alb, alb)
+    assert np.max(np.abs(out["1"][0] - ofu)) < 10 * FLUX_ATOL and np.max(np.abs(out["1"][1] - ofd)) < 10 * FLUX_ATOL
+
+
 def test_fortran_solver_option_binding_reports_errors(pkg):
     """mo_rte_lw's rte_set_solver_option (ecckd_set_solver_option behind it) returns the library's message for an
     unknown name or a value out of range; the driver stops on it like on every other error_msg (no GPU needed)."""

@@ -423,3 +423,45 @@ def test_bench_launches_its_own_ranks(pkg, gpu, tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ncol_total"] == 120000
     assert len(d["per_rank_ms_per_step"]["ranks"]) == 2 and d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL
+
+
+# ------------------------------------------------------------------------------------------------
+# fp64 gas optics over the float32 image of the tables in LDS ("gas_slab_f32")
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("orography", ["default", "shuffled 50-103 kPa"])
+def test_float32_table_image_gives_the_same_bits(pkg, gpu, oracle_mod, orography):
+    """Every table of the ecCKD files is float32 on disk (widened exactly on read, mo_simple_netcdf.F90:44-142), so the
+    fp64 longwave gas optics may stage them in LDS as float32 and widen them when it uses them: "gas_slab_f32" = 0 (fp64
+    slab), 1 (float32 image: 8 instead of 3 pressure rows) and 2 (default: a probe picks per call) give the same bits in
+    tau and in the Planck sources, on the default columns and on surface pressures shuffled over 50-103 kPa (where the
+    probe picks the float32 image); a model whose tables are not float32 numbers never takes it."""
+    import torch
+    import helpers
+    from conftest import LW_FSCK
+    from rte_ecckd_amd import synthetic
+    k = pkg.GasOpticsEcckd()
+    assert k.load(LW_FSCK, device=0) == ""
+    ncol, nlay = 6000, 60
+    cols = synthetic.columns(123, ncol, k.get_press_min())
+    if orography != "default":
+        rng = np.random.default_rng(4)
+        eta = (np.arange(nlay + 1, dtype=np.float64) / nlay) ** 2
+        ptop = cols["plev"][0, 0]
+        ps = 50000 + 53000 * rng.random(ncol)
+        cols["plev"] = ptop + (ps[None, :] - ptop) * eta[:, None]
+    out = {}
+    try:
+        for opt in (0, 1, 2):
+            pkg.set_solver_option("gas_slab_f32", opt)
+            err, tau, lay, inc, dec, sfc = helpers.run_lw_gas_optics(pkg, k, cols, gpu)
+            assert err == ""
+            out[opt] = (tau, lay, inc, dec, sfc)
+    finally:
+        pkg.set_solver_option("gas_slab_f32", 2)
+    for opt in (1, 2):
+        for a, b in zip(out[0], out[opt]):
+            assert np.array_equal(a, b)
+    m = oracle_mod.CkdModel(LW_FSCK)
+    sub = {n: (np.ascontiguousarray(v[..., :256]) if isinstance(v, np.ndarray) and v.shape[-1] == ncol else v) for n, v in cols.items()}
+    otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, sub["plev"], sub["tlay"], sub["tsfc"], helpers.oracle_gas_items(sub), sub["tlev"])
+    assert helpers.max_rel(out[1][0][..., :256], otau) < 1e-12 and np.array_equal(out[1][1][..., :256], olay)

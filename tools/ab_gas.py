@@ -18,6 +18,9 @@ def child(ncol, dtype):
     import bench
     import rte_ecckd_amd as pkg
     L = pkg.lib()
+    for item in filter(None, os.environ.get("ECCKD_AB_OPTS", "").split(",")):     # e.g. gas_slab_f32=1
+        name, _, value = item.partition("=")
+        pkg.set_solver_option(name, float(value))
     dev = torch.device("cuda:0")
     k = pkg.GasOpticsEcckd()
     assert k.load(os.path.join(root, "data", "ecckd-1.2_lw_ckd-definition_climate_fsck-tol0.0161.nc"), device=0) == ""
@@ -52,8 +55,10 @@ if __name__ == "__main__":
     ncol = sys.argv[1] if len(sys.argv) > 1 else "1000000"
     dtype = sys.argv[2] if len(sys.argv) > 2 else "f64"
     libs = sorted(glob.glob(os.path.join(root, "variants_tmp", "lib_v*.so")))
+    optsets = os.environ.get("ECCKD_AB_OPTSETS", "").split(";")      # e.g. "gas_slab_f32=0;gas_slab_f32=1": every variant with each
     for rep in range(2):
         for lib in libs:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ncol, dtype],
-                                 env=dict(os.environ, ECCKD_LIB=lib), capture_output=True, text=True)
-            print(os.path.basename(lib), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "FAILED " + out.stderr[-600:], flush=True)
+            for opts in optsets:
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ncol, dtype],
+                                     env=dict(os.environ, ECCKD_LIB=lib, ECCKD_AB_OPTS=opts), capture_output=True, text=True)
+                print(os.path.basename(lib), opts, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "FAILED " + out.stderr[-600:], flush=True)

@@ -14,6 +14,10 @@ import rte_ecckd_amd as pkg   # noqa: E402
 from rte_ecckd_amd import synthetic   # noqa: E402
 
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+for item in filter(None, os.environ.get("ECCKD_AB_OPTS", "").split(",")):     # e.g. gas_slab_f32=1
+    name, _, value = item.partition("=")
+    pkg.set_solver_option(name, float(value))
+    print("option", name, value)
 nlay = 60
 dev = torch.device("cuda:0")
 k = pkg.GasOpticsEcckd()
