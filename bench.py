@@ -65,7 +65,7 @@ def kernel_source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rte-ecckd_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith(".hip") or f in ("kernels.hpp", "wave_pair.hpp"):
+        if f.endswith(".hip") or f in ("kernels.hpp", "wave_pair.hpp", "sw_two_stream.hpp", "sw_two_stream_body.inc"):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -755,10 +755,10 @@ def main():
 
 
 def main_sw(args):
-    print(json.dumps(sw_measure(args.ncol, args.steps, args.warmup, args.solver_option)), flush=True)
+    print(json.dumps(sw_measure(args.ncol, args.steps, args.warmup, args.solver_option, fused=not args.no_side)), flush=True)
 
 
-def sw_measure(ncol, steps, warmup, solver_option=()):
+def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
     """Secondary line: SW wide-tol0.05 (27 g-points), gas_optics (tau, ssa, g) + rte_sw two-stream, fp64,
     single GPU.  Algorithmic bytes: tau, ssa, g written once and read once = 48 B/cell (+ per-column terms)."""
     import types
@@ -851,19 +851,22 @@ def sw_measure(ncol, steps, warmup, solver_option=()):
         e = k.sw_fluxes(plev, tlay, gc, True, percol["mu0"], alb, alb, fl)
         if e:
             raise SystemExit(e)
-    for _ in range(max(args.warmup, 1)):
-        fstep()
-    torch.cuda.synchronize()
-    L.ecckd_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fstep()
-    torch.cuda.synchronize()
-    ms_f = (time.perf_counter() - t0) / args.steps * 1e3
-    L.ecckd_prof_enable(0)
-    nk = L.ecckd_prof_report(8, names_b, ms, cnt)
-    kf = {names_b.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): ms[i] / max(cnt[i], 1) for i in range(nk)}
-    fused_sw = {"value": cells / (ms_f * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": ms_f,
+    fused_sw = None
+    if fused:
+        for _ in range(max(args.warmup, 1)):
+            fstep()
+        torch.cuda.synchronize()
+        L.ecckd_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        torch.cuda.synchronize()
+        ms_f = (time.perf_counter() - t0) / args.steps * 1e3
+        L.ecckd_prof_enable(0)
+        nk = L.ecckd_prof_report(8, names_b, ms, cnt)
+        kf = {names_b.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): ms[i] / max(cnt[i], 1) for i in range(nk)}
+    if fused:
+        fused_sw = {"value": cells / (ms_f * 1e-3) / 1e6, "unit": "Mcol*lay*gpt/s", "ms_per_step": ms_f,
                 "speedup_vs_api_pair": ms_per_step / ms_f, "kernels_avg_ms": kf, "hbm_bytes_per_cell_between_kernels": 16,
                 "max_abs_flux_diff_vs_api_path_Wm2": max(float((fl.flux_up - ref_up).abs().max()), float((fl.flux_dn - ref_dn).abs().max())),
                 "note": "ecckd_sw_fluxes: gas optics writes the total optical depth only, the solver derives ssa, g = 0 and the "

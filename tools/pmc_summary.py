@@ -19,9 +19,11 @@ import bench  # noqa: E402
 
 
 def short(name):
-    m = re.search(r"gas_fused_kernel<(\w+), \d+, \d+, \w+, \w+, (\d)>", name)
+    m = re.search(r"gas_fused_kernel<(\w+), \d+, \d+, \w+, \w+, (\d)(?:, (\w+))?>", name)
     if m:
         base = {"0": "tau", "1": "gas_lw_fused", "2": "gas_sw"}[m.group(2)]
+        if m.group(1) == "double" and m.group(3) == "float":      # fp64 over the float32 image of the tables ("gas_slab_f32"):
+            return base + "_slab32"                               # with the option on auto this is the launch that returns at once
         return base + ("_f32" if m.group(1) == "float" else "")
     m = re.search(r"rte_lw_kernel<(\w+), \d+, \d+, \w+, \w+, (\w+), \w+>", name)
     if m:
@@ -29,7 +31,12 @@ def short(name):
     m = re.search(r"rte_lw_split_kernel<\d+, \d+, \d+, \w+, \w+, (\w+), \d>", name)
     if m:
         return "rte_lw_fused" if m.group(1) == "true" else "rte_lw_split"
-    for key in ("rte_sw_kernel", "tau_kernel", "planck_kernel", "toa_src_kernel", "lw_gpt_kernel", "sw_gpt_kernel"):
+    m = re.search(r"rte_sw_sys_kernel<(\w+), \w+, \w+, (\w+), \w+>", name)
+    if m:       # (the 4th template argument: ecckd_sw_fluxes' form, which reads the total optical depth only)
+        return "rte_sw" + ("_f32" if m.group(1) == "float" else "") + ("_fused" if m.group(2) == "true" else "")
+    if "rte_sw_kernel" in name:
+        return "rte_sw_two_pass"
+    for key in ("tau_kernel", "planck_kernel", "toa_src_kernel", "lw_gpt_kernel", "sw_gpt_kernel"):
         if key in name:
             return key.replace("_kernel", "")
     return None
