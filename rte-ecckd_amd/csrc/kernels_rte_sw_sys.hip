@@ -37,7 +37,7 @@ constexpr int kSysWaves = 12;   // waves per block: three per SIMD (<= 168 VGPRs
 constexpr int kSysLPW = 5;      // layers per wave
 constexpr int kSysMaxLay = kSysWaves * kSysLPW;
 #ifndef ECCKD_SYS_FMA_CHAIN
-#define ECCKD_SYS_FMA_CHAIN 0
+#define ECCKD_SYS_FMA_CHAIN 1
 #endif
 constexpr bool kSysFmaChain = ECCKD_SYS_FMA_CHAIN != 0;
 constexpr int kSysSpinLimit = 1 << 22;   // polls of a flag before the block gives up (a lost hand-off never hangs the GPU)
@@ -50,8 +50,7 @@ __device__ long long g_sys_times[kSysWaves][8];
 #endif
 
 struct SysLds {
-  int flag_u[kSysWaves];   // sequence number of the (albedo, source) pair waiting in hand-off slot w
-  int flag_d[kSysWaves];   // ... of the (fdn, fdir) pair
+  int unused_[2 * kSysWaves];
   int abort_;              // set when a wait ran into kSysSpinLimit: every later wait returns at once, the fluxes become NaN
   int pad_;
 };
@@ -64,18 +63,62 @@ __device__ __forceinline__ void static_for_sys(F &&f) {
   }
 }
 
+// How a waiting wave polls.  Measured in round 3 (same box, 1e5 columns): no pause between the polls 1.865 ms, s_sleep 1
+// (64 clocks) 1.86, long naps ended by the producer's s_wakeup 1.865 (s_sleep 12) / 1.91 (s_sleep 40), hand-off through a
+// flag word with release / acquire instead of the slot's own empty mark 1.85: the hand-off mechanism is not what a
+// step of the sweeps costs -- the dependent fp64 operations of the recurrences are (~20 clocks each).
+#ifndef ECCKD_SYS_WAKEUP
+#define ECCKD_SYS_WAKEUP 0
+#endif
 #ifndef ECCKD_SYS_SLEEP
-#define ECCKD_SYS_SLEEP 1
+#define ECCKD_SYS_SLEEP 1   // x 64 clocks
 #endif
-// Waits until *flag == seq (set by another wave of this block with publish()).  Wave-uniform: every lane reads the same
-// word and the comparison is scalar.
-__device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
-#ifdef ECCKD_SYS_DEBUG_NOWAIT   // (timing experiments only: the work of the sweeps without their serial dependence)
-  return;
+// Hand-off between neighbouring waves of a block: a slot of two values per lane in LDS.  An empty slot holds a NaN with a
+// payload no computation produces; the producer stores the pair (any number of instructions, any order), the consumer
+// polls the slot itself until BOTH values of EVERY lane have arrived -- the poll that succeeds has already brought the
+// data -- and stores the empty mark back.  One LDS round trip per hand-off instead of data + flag + data, no fences:
+// nothing else is communicated.  (A column whose own value is that very NaN never arrives: the bounded wait gives up
+// and the tile's fluxes are poisoned, see SysLds::abort_.)
+template <typename real> struct SysSlot;
+template <> struct SysSlot<double> {
+  typedef long long bits_t;
+  static constexpr bits_t kEmpty = 0x7FF80000DEADBEEFLL;
+  static __device__ __forceinline__ bits_t bits(double v) { return __double_as_longlong(v); }
+  static __device__ __forceinline__ double empty() { return __longlong_as_double(kEmpty); }
+};
+template <> struct SysSlot<float> {
+  typedef int bits_t;
+  static constexpr bits_t kEmpty = 0x7FC0BEEF;
+  static __device__ __forceinline__ bits_t bits(float v) { return __float_as_int(v); }
+  static __device__ __forceinline__ float empty() { return __int_as_float(kEmpty); }
+};
+template <typename real>
+__device__ __forceinline__ void put_pair(real *slot, real a, real b) {
+  typedef __attribute__((address_space(3))) volatile real lds_v;   // (volatile: stays where it is written, ahead of the next wait)
+  lds_v *p = (lds_v *)slot;
+  p[0] = a;
+  p[64] = b;
+#if ECCKD_SYS_WAKEUP
+  // the waiting waves of the block sleep between their polls (take_pair): wake them now instead of letting eleven waves
+  // poll LDS without a pause -- their reads queue in front of this very store and of the successor's poll
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the pair has reached LDS
+  asm volatile("s_wakeup");
 #endif
+}
+// (slot: this lane's word of the first value; the second one 64 elements on)
+template <typename real>
+__device__ __forceinline__ void take_pair(real *slot, real &a, real &b, int *abort_) {
+  typedef __attribute__((address_space(3))) volatile real lds_v;
+  lds_v *p = (lds_v *)slot;
   int spins = 0;
-  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) {
-    __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP);
+  for (;;) {
+    a = p[0];
+    b = p[64];
+#ifdef ECCKD_SYS_DEBUG_NOWAIT   // (timing experiments only: the work of the sweeps without their serial dependence)
+    break;
+#endif
+    if (__all(SysSlot<real>::bits(a) != SysSlot<real>::kEmpty && SysSlot<real>::bits(b) != SysSlot<real>::kEmpty)) break;
+    if (ECCKD_SYS_SLEEP) __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP);
     if ((++spins & 63) == 0) {
       if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
       if (spins > kSysSpinLimit) {
@@ -84,9 +127,8 @@ __device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
       }
     }
   }
-}
-__device__ __forceinline__ void publish(int *flag, int seq) {
-  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  p[0] = SysSlot<real>::empty();
+  p[64] = SysSlot<real>::empty();
 }
 
 // real: storage and arithmetic type.  FAST / CLAMP: as rte_sw_kernel.  DERIVE: fused shortwave path (RteSwArgs::derive).
@@ -111,13 +153,14 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
   const int s0 = w * LPW;                           // first layer of this wave, counted from the top
   const int nl = nlay - s0 < 0 ? 0 : (nlay - s0 < LPW ? nlay - s0 : LPW);
   if (threadIdx.x < 2 * NW + 2) reinterpret_cast<int *>(ctl)[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < NW * 4 * 64; i += 64 * NW) hand[i] = SysSlot<real>::empty();
   if (threadIdx.x < 256) bandmap[threadIdx.x] = a.gpt2band[threadIdx.x];
   __syncthreads();
   if (w >= nwa) return;                             // (no barrier below this line)
   const bool top_wave = w == 0, bottom_wave = w == nwa - 1;
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay, lstep = a.top_at_1 ? 1 : -1;
-  real *hu_alb = hand + ((long)w * 4 + 0) * 64 + lane, *hu_src = hand + ((long)w * 4 + 1) * 64 + lane;
-  real *hd_fdn = hand + ((long)w * 4 + 2) * 64 + lane, *hd_dir = hand + ((long)w * 4 + 3) * 64 + lane;
+  real *hu_alb = hand + ((long)w * 4 + 0) * 64 + lane;
+  real *hd_fdn = hand + ((long)w * 4 + 2) * 64 + lane;
   const real k_floor = (real)a.k_floor;
   const real gw = (real)a.gw;
   double *my_up = acc_up + s0 * 64 + lane, *my_dn = acc_dn + s0 * 64 + lane, *my_dir = acc_dir + s0 * 64 + lane;
@@ -127,7 +170,6 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
   const int gchunk = a.sys_gchunk > 0 ? a.sys_gchunk : ng;
   const int nchunks = (ng + gchunk - 1) / gchunk;
   const long nunits = tail_first + (ntiles - tail_first) * nchunks;
-  int seq = 0;   // hand-off sequence number: one per (unit, g-point), the same in every wave of the block
 
   for (long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     long tile = unit;
@@ -237,7 +279,6 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       real st[LPW][6];
       real albedo = real(0), nsrc = real(0);
       if (step) {
-        ++seq;
         SYS_STAMP(0);
         // ---- P ----
         if (parking) {
@@ -259,14 +300,14 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
         // ---- U: adding, bottom -> top.  The source is carried normalised by the direct beam at its own level (the
         // beam is only known on the way down): src(l) = nsrc(l) * F_dir(l), F_dir(l+1) = Tnoscat(l) * F_dir(l) ----
         SYS_STAMP(2);
-        if (!bottom_wave) wait_flag(&ctl->flag_u[w], seq, &ctl->abort_);
+        real h_alb = real(0), h_src = real(0);
+        if (!bottom_wave) take_pair(hu_alb, h_alb, h_src, &ctl->abort_);
         SYS_STAMP(3);
 #ifndef ECCKD_SYS_NOPRIO
         // the sweeps are the critical path of the block: the wave that holds the token issues ahead of the waves of
         // its SIMD that are still computing coefficients
         __builtin_amdgcn_s_setprio(3);
 #endif
-        const real h_alb = *hu_alb, h_src = *hu_src;   // (read by the bottom wave too, and ignored: no pointer select)
         albedo = bottom_wave ? pb0 : h_alb;
         nsrc = bottom_wave ? pb1 : h_src;
         if (bottom_wave && g + 1 < g_end) load_albedos(g + 1);
@@ -276,9 +317,10 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
           if (FULL || l < nl) {
             const real Rdif = st[l][0], Tdif = st[l][1], Rdir = st[l][2], Tdir = st[l][3], Tn = st[l][4];
             // adding, Eq 10 / 11 / 9.  Eq 11 is divided by F_dir(l): src_up = Rdir*F_dir(l), src_dn = Tdir*F_dir(l),
-            // src(l+1) = nsrc*Tnoscat*F_dir(l).  (kSysFmaChain: the multiply-add pairs of the recurrence as FMAs -- the
-            // wave that holds the token issues one fp64 instruction every ~10 clocks -- measured 5 % on the chain and
-            // nothing on the kernel: off, every operation is rounded on its own as in kernels_rte_sw.hip.)
+            // src(l+1) = nsrc*Tnoscat*F_dir(l).  Fast arithmetic mode (kSysFmaChain): the multiply-add pairs of the recurrence
+            // are FMAs -- the wave that holds the token issues one fp64 instruction every ~10 clocks, and every instruction
+            // less shortens the critical path of the block: -5.5 % on the kernel, fluxes unchanged to 1e-13 W m-2.  The
+            // reference-order mode rounds every operation on its own, as kernels_rte_sw.hip does.
             real denom, A;
             if constexpr (FAST && kSysFmaChain) {
               denom = rcp<true>(fma(-Rdif, albedo, real(1)));
@@ -301,9 +343,7 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
           }
         }
         if (!top_wave) {
-          hu_alb[-4 * 64] = albedo;   // slot of the wave above
-          hu_src[-4 * 64] = nsrc;
-          publish(&ctl->flag_u[w - 1], seq);
+          put_pair(hu_alb - 4 * 64, albedo, nsrc);   // slot of the wave above
 #ifndef ECCKD_SYS_NOPRIO
           __builtin_amdgcn_s_setprio(0);   // (waiting for the token to come back down)
 #endif
@@ -324,12 +364,12 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       if (step) {
         // ---- D: direct beam and fluxes, top -> bottom (Eq 12, 13) ----
         SYS_STAMP(4);
-        if (!top_wave) wait_flag(&ctl->flag_d[w], seq, &ctl->abort_);
+        real h_fdn = real(0), h_dir = real(0);
+        if (!top_wave) take_pair(hd_fdn, h_fdn, h_dir, &ctl->abort_);
         SYS_STAMP(5);
 #ifndef ECCKD_SYS_NOPRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
-        const real h_fdn = *hd_fdn, h_dir = *hd_dir;
         real fdir = top_wave ? ptoa * mu0 : h_dir;
         real fdn = top_wave ? real(0) : h_fdn;
         if (top_wave && g + 1 < g_end) load_toa(g + 1);
@@ -354,9 +394,7 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
           }
         }
         if (!bottom_wave) {
-          hd_fdn[4 * 64] = fdn;       // slot of the wave below
-          hd_dir[4 * 64] = fdir;
-          publish(&ctl->flag_d[w + 1], seq);
+          put_pair(hd_fdn + 4 * 64, fdn, fdir);     // slot of the wave below
         }
 #ifndef ECCKD_SYS_NOPRIO
         __builtin_amdgcn_s_setprio(0);
