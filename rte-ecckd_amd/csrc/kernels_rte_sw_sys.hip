@@ -50,7 +50,8 @@ __device__ long long g_sys_times[kSysWaves][8];
 #endif
 
 struct SysLds {
-  int unused_[2 * kSysWaves];
+  int flag_u[kSysWaves];   // sequence number of the (albedo, source) pair waiting in hand-off slot w
+  int flag_d[kSysWaves];   // ... of the (fdn, fdir) pair
   int abort_;              // set when a wait ran into kSysSpinLimit: every later wait returns at once, the fluxes become NaN
   int pad_;
 };
@@ -63,62 +64,24 @@ __device__ __forceinline__ void static_for_sys(F &&f) {
   }
 }
 
-// How a waiting wave polls.  Measured in round 3 (same box, 1e5 columns): no pause between the polls 1.865 ms, s_sleep 1
-// (64 clocks) 1.86, long naps ended by the producer's s_wakeup 1.865 (s_sleep 12) / 1.91 (s_sleep 40), hand-off through a
-// flag word with release / acquire instead of the slot's own empty mark 1.85: the hand-off mechanism is not what a
-// step of the sweeps costs -- the dependent fp64 operations of the recurrences are (~20 clocks each).
-#ifndef ECCKD_SYS_WAKEUP
-#define ECCKD_SYS_WAKEUP 0
-#endif
+// Hand-off between neighbouring waves of a block: the pair of values of every lane in an LDS slot, then a flag word
+// with the sequence number of the step (release); the consumer polls the flag -- one broadcast dword per poll -- and
+// reads its pair after it (acquire).  Measured in round 3 (same box, 1e5 columns, kernel times): this form 1.75 ms;
+// no flag, the slot's own "empty" NaN mark polled instead (one LDS round trip less, but every poll moves 1 KiB per wave
+// and eleven waves poll) 1.84; that with long naps ended by the producer's s_wakeup 1.87; s_sleep 0 / 1 / 2 between
+// the polls: no difference.
 #ifndef ECCKD_SYS_SLEEP
 #define ECCKD_SYS_SLEEP 1   // x 64 clocks
 #endif
-// Hand-off between neighbouring waves of a block: a slot of two values per lane in LDS.  An empty slot holds a NaN with a
-// payload no computation produces; the producer stores the pair (any number of instructions, any order), the consumer
-// polls the slot itself until BOTH values of EVERY lane have arrived -- the poll that succeeds has already brought the
-// data -- and stores the empty mark back.  One LDS round trip per hand-off instead of data + flag + data, no fences:
-// nothing else is communicated.  (A column whose own value is that very NaN never arrives: the bounded wait gives up
-// and the tile's fluxes are poisoned, see SysLds::abort_.)
-template <typename real> struct SysSlot;
-template <> struct SysSlot<double> {
-  typedef long long bits_t;
-  static constexpr bits_t kEmpty = 0x7FF80000DEADBEEFLL;
-  static __device__ __forceinline__ bits_t bits(double v) { return __double_as_longlong(v); }
-  static __device__ __forceinline__ double empty() { return __longlong_as_double(kEmpty); }
-};
-template <> struct SysSlot<float> {
-  typedef int bits_t;
-  static constexpr bits_t kEmpty = 0x7FC0BEEF;
-  static __device__ __forceinline__ bits_t bits(float v) { return __float_as_int(v); }
-  static __device__ __forceinline__ float empty() { return __int_as_float(kEmpty); }
-};
-template <typename real>
-__device__ __forceinline__ void put_pair(real *slot, real a, real b) {
-  typedef __attribute__((address_space(3))) volatile real lds_v;   // (volatile: stays where it is written, ahead of the next wait)
-  lds_v *p = (lds_v *)slot;
-  p[0] = a;
-  p[64] = b;
-#if ECCKD_SYS_WAKEUP
-  // the waiting waves of the block sleep between their polls (take_pair): wake them now instead of letting eleven waves
-  // poll LDS without a pause -- their reads queue in front of this very store and of the successor's poll
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the pair has reached LDS
-  asm volatile("s_wakeup");
-#endif
-}
-// (slot: this lane's word of the first value; the second one 64 elements on)
-template <typename real>
-__device__ __forceinline__ void take_pair(real *slot, real &a, real &b, int *abort_) {
-  typedef __attribute__((address_space(3))) volatile real lds_v;
-  lds_v *p = (lds_v *)slot;
-  int spins = 0;
-  for (;;) {
-    a = p[0];
-    b = p[64];
+// Waits until *flag == seq (set by another wave of this block with publish()).  Wave-uniform: every lane reads the same
+// word and the comparison is scalar.
+__device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
 #ifdef ECCKD_SYS_DEBUG_NOWAIT   // (timing experiments only: the work of the sweeps without their serial dependence)
-    break;
+  return;
 #endif
-    if (__all(SysSlot<real>::bits(a) != SysSlot<real>::kEmpty && SysSlot<real>::bits(b) != SysSlot<real>::kEmpty)) break;
-    if (ECCKD_SYS_SLEEP) __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP);
+  int spins = 0;
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) {
+    __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP);
     if ((++spins & 63) == 0) {
       if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
       if (spins > kSysSpinLimit) {
@@ -127,9 +90,21 @@ __device__ __forceinline__ void take_pair(real *slot, real &a, real &b, int *abo
       }
     }
   }
-  p[0] = SysSlot<real>::empty();
-  p[64] = SysSlot<real>::empty();
 }
+__device__ __forceinline__ void publish(int *flag, int seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 1/x for the adding recurrence of the fast arithmetic mode: hardware reciprocal (relative error <= 2^-23 in fp64) and ONE
+// third-order step, r = r0 + r0*(e + e*e), e = 1 - x*r0: error e^3 ~ 2^-69, i.e. the correctly rounded reciprocal up to
+// the last bit -- three dependent operations behind the v_rcp instead of the four of two Newton steps (rcp<true>): the
+// reciprocal sits on the critical path of the block once per layer.
+__device__ __forceinline__ double rcp_chain(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r0, 1.);
+  return fma(fma(e, e, e), r0, r0);
+}
+__device__ __forceinline__ float rcp_chain(float x) { return rcp<true>(x); }
 
 // real: storage and arithmetic type.  FAST / CLAMP: as rte_sw_kernel.  DERIVE: fused shortwave path (RteSwArgs::derive).
 // FULL: every wave that owns layers owns LPW of them (nlay a multiple of LPW): no per-layer branches.
@@ -153,7 +128,6 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
   const int s0 = w * LPW;                           // first layer of this wave, counted from the top
   const int nl = nlay - s0 < 0 ? 0 : (nlay - s0 < LPW ? nlay - s0 : LPW);
   if (threadIdx.x < 2 * NW + 2) reinterpret_cast<int *>(ctl)[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < NW * 4 * 64; i += 64 * NW) hand[i] = SysSlot<real>::empty();
   if (threadIdx.x < 256) bandmap[threadIdx.x] = a.gpt2band[threadIdx.x];
   __syncthreads();
   if (w >= nwa) return;                             // (no barrier below this line)
@@ -171,6 +145,7 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
   const int nchunks = (ng + gchunk - 1) / gchunk;
   const long nunits = tail_first + (ntiles - tail_first) * nchunks;
 
+  int seq = 0;   // hand-off sequence number: one per (unit, g-point), the same in every wave of the block
   for (long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     long tile = unit;
     int g_begin = 0, g_end = ng;
@@ -279,6 +254,7 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       real st[LPW][6];
       real albedo = real(0), nsrc = real(0);
       if (step) {
+        ++seq;
         SYS_STAMP(0);
         // ---- P ----
         if (parking) {
@@ -300,14 +276,14 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
         // ---- U: adding, bottom -> top.  The source is carried normalised by the direct beam at its own level (the
         // beam is only known on the way down): src(l) = nsrc(l) * F_dir(l), F_dir(l+1) = Tnoscat(l) * F_dir(l) ----
         SYS_STAMP(2);
-        real h_alb = real(0), h_src = real(0);
-        if (!bottom_wave) take_pair(hu_alb, h_alb, h_src, &ctl->abort_);
+        if (!bottom_wave) wait_flag(&ctl->flag_u[w], seq, &ctl->abort_);
         SYS_STAMP(3);
 #ifndef ECCKD_SYS_NOPRIO
         // the sweeps are the critical path of the block: the wave that holds the token issues ahead of the waves of
         // its SIMD that are still computing coefficients
         __builtin_amdgcn_s_setprio(3);
 #endif
+        const real h_alb = hu_alb[0], h_src = hu_alb[64];   // (read by the bottom wave too, and ignored: no pointer select)
         albedo = bottom_wave ? pb0 : h_alb;
         nsrc = bottom_wave ? pb1 : h_src;
         if (bottom_wave && g + 1 < g_end) load_albedos(g + 1);
@@ -323,7 +299,7 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
             // reference-order mode rounds every operation on its own, as kernels_rte_sw.hip does.
             real denom, A;
             if constexpr (FAST && kSysFmaChain) {
-              denom = rcp<true>(fma(-Rdif, albedo, real(1)));
+              denom = rcp_chain(fma(-Rdif, albedo, real(1)));
               A = Tdif * denom;
               dn[l] = denom;
               st[l][2] = albedo;
@@ -343,7 +319,9 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
           }
         }
         if (!top_wave) {
-          put_pair(hu_alb - 4 * 64, albedo, nsrc);   // slot of the wave above
+          hu_alb[-4 * 64] = albedo;   // slot of the wave above
+          hu_alb[-3 * 64] = nsrc;
+          publish(&ctl->flag_u[w - 1], seq);
 #ifndef ECCKD_SYS_NOPRIO
           __builtin_amdgcn_s_setprio(0);   // (waiting for the token to come back down)
 #endif
@@ -364,8 +342,8 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       if (step) {
         // ---- D: direct beam and fluxes, top -> bottom (Eq 12, 13) ----
         SYS_STAMP(4);
-        real h_fdn = real(0), h_dir = real(0);
-        if (!top_wave) take_pair(hd_fdn, h_fdn, h_dir, &ctl->abort_);
+        if (!top_wave) wait_flag(&ctl->flag_d[w], seq, &ctl->abort_);
+        const real h_fdn = hd_fdn[0], h_dir = hd_fdn[64];
         SYS_STAMP(5);
 #ifndef ECCKD_SYS_NOPRIO
         __builtin_amdgcn_s_setprio(3);
@@ -382,7 +360,9 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
             const real fdir_next = Tn * fdir;
             const real src_next = nsrc_next * fdir_next;
             if constexpr (FAST && kSysFmaChain) {
-              fdn = fma(C, fdir, fma(B, src_next, A * fdn));                 // Eq 12 with denom multiplied in
+              // Eq 12 with denom multiplied in, associated so that the recurrence of the diffuse flux is ONE dependent
+              // operation per layer (the direct-beam terms run ahead of it): a dependent fp64 operation costs ~20 clocks
+              fdn = fma(A, fdn, fma(B, src_next, C * fdir));
               fu[l] = fma(fdn, alb_next, src_next);                          // Eq 13
             } else {
               fdn = A * fdn + B * src_next + C * fdir;
@@ -394,7 +374,9 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
           }
         }
         if (!bottom_wave) {
-          put_pair(hd_fdn + 4 * 64, fdn, fdir);     // slot of the wave below
+          hd_fdn[4 * 64] = fdn;       // slot of the wave below
+          hd_fdn[5 * 64] = fdir;
+          publish(&ctl->flag_d[w + 1], seq);
         }
 #ifndef ECCKD_SYS_NOPRIO
         __builtin_amdgcn_s_setprio(0);
