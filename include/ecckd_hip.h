@@ -400,7 +400,10 @@ int ecckd_get_arithmetic(void);
  * Version switches of the solvers (process-wide; read once per call).  RTE-RRTMGP is an un-pinned dependency
  * of the reference (.github/workflows/continuous-integration.yml:98-102 checks out its default branch), and a few
  * details of rte_lw / rte_sw changed between releases.  The defaults are the v1.5-era forms; a host linked
- * against a later RTE-RRTMGP selects the matching forms here.  bench.py prints the active values.
+ * against a later RTE-RRTMGP selects the matching forms here.  bench.py prints the active values.  PARITY UNPINNED: both
+ * forms of every switch restate RTE-RRTMGP from the published sources -- the library is not in the reference tree and
+ * the reference holds no fixture for it; the tests check the HIP solvers against this repository's
+ * CPU restatement with the same switch, nothing more.
  *   "lw_tau_thresh"          lw_source_noscat uses the series below this tau*D (default sqrt(epsilon(1._wp));
  *                            later releases: sqrt(sqrt(epsilon)));  <= 0 restores the default
  *   "lw_series_terms"        2: tau*(0.5 - tau/3) (default);  3: tau*(0.5 + tau*(-1/3 + tau/8))

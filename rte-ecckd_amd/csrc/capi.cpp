@@ -1546,8 +1546,11 @@ int ecckd_gas_optics_lw_tau(const ecckd_model_t *m, int ncol, int nlay, const do
 // Scratch (in doubles) the fused solver needs besides tau: none at 60 layers (the Planck sources are recomputed inside the
 // layer-split solver); any other layer count takes the general route -- Planck kernel into scratch, then the
 // register-resident solver with shared level sources -- and needs room for the sources and that solver's ring.
+static bool fused_lw_kernels_apply(const ecckd_model *m, int nlay) {
+  return nlay == 60 && ecckd::rte_lw_planck_fits(m->ng, m->ntp);   // (a 64-g Planck table does not fit: general route)
+}
 static size_t fused_scratch_doubles(const ecckd_model *m, int ncol, int nlay) {
-  if (nlay == 60) return 0;
+  if (fused_lw_kernels_apply(m, nlay)) return 0;
   const size_t n3 = (size_t)ncol * nlay * m->ng;
   return 3 * n3 + (size_t)ncol * m->ng + 32 + ecckd::rte_lw_scratch_bytes(ncol, nlay, m->ng) / sizeof(double);
 }
@@ -1572,7 +1575,7 @@ static int rte_lw_fused_dev(const ecckd_model *m, int ncol, int nlay, int top_at
     a.wts[k] = kGaussWts[n_gauss_angles - 1][k];
   }
   a.tau = tau; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux; a.flux_up = flux_up; a.flux_dn = flux_dn;
-  if (nlay == 60) {
+  if (fused_lw_kernels_apply(m, nlay)) {
     ProfScope prof("rte_lw_fused", stream);
     HIPCHK(ecckd::launch_rte_lw_planck(a, m->dbuf + m->off_planck, m->ntp, m->temperature_planck[0],
                                        m->temperature_planck[1] - m->temperature_planck[0], tlay, tlev, tsfc, stream));

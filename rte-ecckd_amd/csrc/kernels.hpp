@@ -211,6 +211,7 @@ hipError_t launch_sum_planes(const double *planes, int nplanes, size_t n, double
 hipError_t launch_rte_lw(const RteLwArgs &a, hipStream_t s);
 // layer-split form (kernels_rte_lw_split.hip): fp64, 60 layers
 bool rte_lw_split_applies(const RteLwArgs &a);
+bool rte_lw_planck_fits(int ng, int ntp);   // the Planck-recomputing form: does the model's table fit in LDS?
 hipError_t launch_rte_lw_split(const RteLwArgs &a, hipStream_t s);
 // ... with the Planck sources recomputed in the solver from tlay(ncol,nlay), tlev(ncol,nlay+1), tsfc(ncol) and the
 // model's table planck(ng,ntp) (a.lay_source / lev_source_* / sfc_source are not read)

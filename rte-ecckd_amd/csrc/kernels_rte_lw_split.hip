@@ -304,6 +304,14 @@ hipError_t launch_split(const RteLwArgs &a, const PlanckTab &pt, const double *t
 
 }  // namespace
 
+// LDS of the Planck-recomputing form (launch_seg<..., PLANCK = true>: 15 layers per wave, 4 waves, 32 columns): does the
+// model's Planck table fit next to the accumulators?  (The shipped 32 / 36-g models do; a 64-g table does not.)
+bool rte_lw_planck_fits(int ng, int ntp) {
+  constexpr int SEG = 15, NW = 4, CW = 32, NG = split_groups(true);
+  const size_t lds = sizeof(double) * (NG * (2 * (size_t)(SEG * NW + 1) * CW + 2 * NW * 3 * 64) + (size_t)ntp * planck_stride(ng));
+  return lds <= (size_t)kLdsBudget;
+}
+
 bool rte_lw_split_applies(const RteLwArgs &a) {
   return !a.f32 && a.nlay == 60 && a.ncol > 0;
 }

@@ -465,3 +465,43 @@ def test_float32_table_image_gives_the_same_bits(pkg, gpu, oracle_mod, orography
     sub = {n: (np.ascontiguousarray(v[..., :256]) if isinstance(v, np.ndarray) and v.shape[-1] == ncol else v) for n, v in cols.items()}
     otau, olay, oinc, odec, osfc, _ = oracle_mod.gas_optics_int(m, sub["plev"], sub["tlay"], sub["tsfc"], helpers.oracle_gas_items(sub), sub["tlev"])
     assert helpers.max_rel(out[1][0][..., :256], otau) < 1e-12 and np.array_equal(out[1][1][..., :256], olay)
+
+
+def test_fused_lw_path_with_a_64_g_point_model(pkg, gpu, oracle_mod):
+    """the Planck-recomputing solver of ecckd_lw_fluxes keeps the model's Planck table in LDS; the 231 x 64
+    table of a 64-g-point model does not fit next to its accumulators.  Such a model takes the general route (sources
+    through library scratch) at 60 layers too -- same fluxes as gas_optics + rte_lw -- instead of failing at launch.
+    (Tables that are not float32 numbers: "gas_slab_f32" never applies to this model.)"""
+    import torch
+    import helpers
+    from conftest import LW_FSCK
+    from rte_ecckd_amd import synthetic
+    m = oracle_mod.CkdModel(LW_FSCK)
+    rng = np.random.default_rng(64)
+    ng = 64
+    tabs = []
+    for name, tb in zip(m.gas[:3], m.tables[:3]):
+        c = tb["coefficient"]
+        big = np.concatenate([c, c * rng.uniform(0.5, 1.5, c.shape)], axis=-1)            # (nv, nt, np, 64)
+        tabs.append(dict(name=name, code=tb["code"], composite_only=0, mole_fraction=tb.get("mole_fraction"),
+                         reference_mole_fraction=tb["reference_mole_fraction"], coefficient=big))
+    planck = np.concatenate([m.planck_function, m.planck_function * 0.37], axis=-1)       # (ntp, 64)
+    k = pkg.GasOpticsEcckd()
+    assert k.init_from_tables(m.log_pressure, m.temperature, tabs, planck=(m.temperature_planck, planck), device=0) == ""
+    assert k.get_ngpt() == ng
+    ncol, nlay = 300, 60
+    cols = synthetic.columns(9, ncol, float(np.exp(m.log_pressure[0])))
+    t = T(gpu)
+    names = list(m.gas[:3])
+    gc = helpers.product_gas_concs(pkg, cols, t, names)
+    plev, tlay, tlev, tsfc = t(cols["plev"]), t(cols["tlay"]), t(cols["tlev"]), t(cols["tsfc"])
+    emis = t(cols["sfc_emis"][:, None])
+    op = pkg.OpticalProps1scl(); op.alloc_1scl(ncol, nlay, k, like=plev)
+    src = pkg.SourceFuncLW(); src.alloc(ncol, nlay, k, like=plev)
+    assert k.gas_optics(None, plev, tlay, tsfc, gc, op, src, tlev=tlev) == ""
+    fl = pkg.FluxesBroadband(*(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(2)))
+    assert pkg.rte_lw(op, True, src, emis, fl) == ""
+    f2 = pkg.FluxesBroadband(*(torch.empty((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(2)))
+    assert k.lw_fluxes(plev, tlay, tsfc, tlev, gc, True, emis, f2) == ""
+    assert float((fl.flux_up - f2.flux_up).abs().max()) < FLUX_ATOL and float((fl.flux_dn - f2.flux_dn).abs().max()) < FLUX_ATOL
+    assert float(fl.flux_up.min()) > 0
