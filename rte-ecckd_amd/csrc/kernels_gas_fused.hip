@@ -166,8 +166,11 @@ __global__ void __launch_bounds__(256) spread_probe_kernel(const real *plev, int
 // disk (widened exactly on read, mo_simple_netcdf.F90:44-142), so the slab and the Planck table can be staged as the
 // float32 they are -- half the LDS -- and widened again (v_cvt_f64_f32, exact) when they are used: the same bits.  The
 // host checks that every value is float32-representable (FusedArgs::slab32).
+#ifndef ECCKD_F32_WAVES
+#define ECCKD_F32_WAVES 2
+#endif
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
-__global__ void __launch_bounds__(kBlock) gas_fused_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES : 2)) gas_fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   sreal *lds = reinterpret_cast<sreal *>(lds_raw);
   typedef sreal double2_t __attribute__((ext_vector_type(2)));   // (two consecutive g-points as they sit in LDS)
@@ -832,7 +835,11 @@ void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
 }
 
 // LDS a block may take: all of a CU's (one block per CU), or ECCKD_FUSED_LDS_KB for experiments with several blocks per CU
-size_t lds_budget() {
+size_t lds_budget(int f32 = 0) {
+#ifdef ECCKD_F32_LDS_KB      // (experiment: two single-precision blocks per CU)
+  if (f32 == 1) return (size_t)ECCKD_F32_LDS_KB * 1024;
+#endif
+  (void)f32;
 #ifdef ECCKD_FUSED_LDS_KB
   return (size_t)ECCKD_FUSED_LDS_KB * 1024;
 #else
@@ -851,7 +858,7 @@ int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, i
   pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
   const int ngp = (ng + GC - 1) / GC * GC;
   const size_t esz = f32 ? sizeof(float) : sizeof(double);
-  const size_t budget = lds_budget();
+  const size_t budget = lds_budget(f32);
   int R = 0;
   for (int r = 2; r <= np; ++r) {
     if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows, f32 == 2 ? 2 : 1).total <= budget) R = r;
@@ -995,7 +1002,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, store);
   const size_t lds = (store ? sizeof(float) : sizeof(double)) *
                      (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw, store == 2 ? 2 : 1).total;
-  if (lds > lds_budget()) return hipErrorInvalidValue;
+  if (lds > lds_budget(store)) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full
   const long ntiles = ((long)t.ncol + kBlock - 1) / kBlock;

@@ -9,7 +9,7 @@ for f in capi.cpp model.cpp cdf1.cpp nc_capi.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -c $f -o $d/${f%.*}.o
 done
 # the kernels are not under test here: reuse the objects of the regular build (python -c 'import rte_ecckd_amd as p; p.build()')
-for f in kernels_gas_fused kernels_tau kernels_planck kernels_rte_lw kernels_rte_lw_split kernels_rte_sw kernels_rte_gpt; do
+for f in kernels_gas_fused kernels_tau kernels_planck kernels_rte_lw kernels_rte_lw_split kernels_rte_sw kernels_rte_sw_sys kernels_rte_gpt; do
   cp ../build/obj/$f.o $d/$f.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fsanitize=address,undefined -Wl,-rpath,/opt/rocm/lib -o $d/librte_ecckd_hip_asan.so $d/*.o
