@@ -625,27 +625,20 @@ __global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES :
                 if (pair_major ? s == NB - 1 : pi_ == NLI + NBI - 1) {
 #pragma unroll
                   for (int g = pair_major ? g0 : 0; g < (pair_major ? g0 + 2 : GC); g += 2) {
-                    if (FULL || gb + g + 1 < ng) {
+                    // planes of this pair that exist: both, or (g-point counts that are not a multiple of the chunk) only the
+                    // first one -- then the half-wave that holds it stores alone -- or none
+                    const int npl = FULL ? 2 : ng - (gb + g);
+                    if (FULL || npl >= 1) {
                       if (MODE == MODE_SW) {
                         const real r0 = moles * P(t.rayleigh)[gb + g], r1 = moles * P(t.rayleigh)[gb + g + 1];   // :316
                         const real t0_ = acc[g] + r0, t1_ = acc[g + 1] + r1;                                 // :456
-                        store_pair<real>(w_tau, plane2, voff, coff, t0_, t1_, masked, active);
+                        store_pair<real>(w_tau, plane2, voff, coff, t0_, t1_, masked, active, npl, upper);
                         if (t.ssa) {                                                                          // :459-460
-                          store_pair<real>(w_ssa, plane2, voff, coff, r0 / t0_, r1 / t1_, masked, active);
-                          store_pair<real>(w_g, plane2, voff, coff, real(0), real(0), masked, active);
+                          store_pair<real>(w_ssa, plane2, voff, coff, r0 / t0_, r1 / t1_, masked, active, npl, upper);
+                          store_pair<real>(w_g, plane2, voff, coff, real(0), real(0), masked, active, npl, upper);
                         }
                       } else {
-                        store_pair<real>(w_tau, plane2, voff, coff, acc[g], acc[g + 1], masked, active);
-                      }
-                    } else if (gb + g < ng && active) {   // odd ng: last g-point alone
-                      const long o = c + (long)ncol * (j + (long)nlay * (gb + g));
-                      if (MODE == MODE_SW) {
-                        const real ray = moles * P(t.rayleigh)[gb + g];
-                        const real tt = acc[g] + ray;
-                        Q(t.tau)[o] = tt;
-                        if (t.ssa) { Q(t.ssa)[o] = ray / tt; Q(t.g)[o] = real(0); }
-                      } else {
-                        Q(t.tau)[o] = acc[g];
+                        store_pair<real>(w_tau, plane2, voff, coff, acc[g], acc[g + 1], masked, active, npl, upper);
                       }
                     }
                   }
@@ -653,8 +646,7 @@ __global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES :
               } else {
                 constexpr int k = pi_ - NLI - NBI;
                 constexpr int g = 2 * (k < NP2 ? k : k - NP2);
-                const bool both = FULL || gb + g + 1 < ng;
-                const long o1 = c + (long)ncol * (j + (long)nlay * (gb + g));   // odd ng: last g-point alone
+                const int npl = FULL ? 2 : ng - (gb + g);   // planes of this pair that exist (see the tau stores)
                 if constexpr (k < NP2) {
                   real vl[2], v1[2];
 #pragma unroll
@@ -662,27 +654,18 @@ __global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES :
                     vl[q] = div_pi(qlay.w0 * (real)b[0][q] + qlay.w1 * (real)b[1][q], pi, rpi);
                     v1[q] = div_pi(ql1.w0 * (real)b[2][q] + ql1.w1 * (real)b[3][q], pi, rpi);
                   }
-                  if (both) {
-                    store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], masked, active);
+                  if (FULL || npl >= 1) {
+                    store_pair<real>(w_lay, plane2, voff, coff, vl[0], vl[1], masked, active, npl, upper);
                     if (a.tlev) {                                                    // :423-424
-                      store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], masked, active);
-                      if (has_next) store_pair<real>(w_decn, plane2, voff, coff, v1[0], v1[1], masked, active);
-                    }
-                  } else if (gb + g < ng && active) {
-                    Q(a.lay_source)[o1] = vl[0];
-                    if (a.tlev) {
-                      Q(a.lev_source_inc)[o1] = v1[0];
-                      if (has_next) Q(a.lev_source_dec)[o1 + ncol] = v1[0];
+                      store_pair<real>(w_inc, plane2, voff, coff, v1[0], v1[1], masked, active, npl, upper);
+                      if (has_next) store_pair<real>(w_decn, plane2, voff, coff, v1[0], v1[1], masked, active, npl, upper);
                     }
                   }
                 } else {
                   real v0[2];
 #pragma unroll
                   for (int q = 0; q < 2; ++q) v0[q] = div_pi(ql0.w0 * (real)b[0][q] + ql0.w1 * (real)b[1][q], pi, rpi);
-                  if (a.tlev) {
-                    if (both) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], masked, active);
-                    else if (gb + g < ng && active) Q(a.lev_source_dec)[o1] = v0[0];
-                  }
+                  if (a.tlev && (FULL || npl >= 1)) store_pair<real>(w_dec0, plane2, voff, coff, v0[0], v0[1], masked, active, npl, upper);
                 }
               }
             }

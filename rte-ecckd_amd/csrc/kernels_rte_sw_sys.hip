@@ -73,6 +73,9 @@ __device__ __forceinline__ void static_for_sys(F &&f) {
 #ifndef ECCKD_SYS_SLEEP
 #define ECCKD_SYS_SLEEP 1   // x 64 clocks
 #endif
+#ifndef ECCKD_SYS_LIGHT_FENCES
+#define ECCKD_SYS_LIGHT_FENCES 0
+#endif
 // Waits until *flag == seq (set by another wave of this block with publish()).  Wave-uniform: every lane reads the same
 // word and the comparison is scalar.
 __device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
@@ -80,7 +83,13 @@ __device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
   return;
 #endif
   int spins = 0;
+#if ECCKD_SYS_LIGHT_FENCES
+  // (LDS executes the DS instructions of a wave in order: the producer's flag store cannot overtake its data stores and
+  // this wave's data reads cannot overtake the flag read whose value it has waited for -- compiler fences are enough)
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) {
+#else
   while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) {
+#endif
     __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP);
     if ((++spins & 63) == 0) {
       if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
@@ -90,9 +99,17 @@ __device__ __forceinline__ void wait_flag(int *flag, int seq, int *abort_) {
       }
     }
   }
+#if ECCKD_SYS_LIGHT_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 __device__ __forceinline__ void publish(int *flag, int seq) {
+#if ECCKD_SYS_LIGHT_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 // 1/x for the adding recurrence of the fast arithmetic mode: hardware reciprocal (relative error <= 2^-23 in fp64) and ONE

@@ -99,9 +99,11 @@ __device__ __forceinline__ void pair_exchange(float &v0, float &v1) {
 // The stores are buffer stores: descriptor (SGPRs, rebuilt from `base` with three scalar instructions) + the per-lane
 // 32-bit offset, no vector address arithmetic.  (global_store with the 64-bit address built per store cost one
 // v_lshl_add_u64 each: instruction selection does not fold a zero-extension hoisted out of the loop.)
+//   nplanes (wave-uniform): 2 = both planes exist; 1 = plane g is the last g-point of the array (g-point counts that are
+//   not a multiple of the chunk): only the half-wave that holds plane g stores.  `upper`: this lane is in that other half.
 template <typename real>
 __device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned voff, unsigned coff, real v0, real v1,
-                                           bool masked, bool active) {
+                                           bool masked, bool active, int nplanes = 2, bool upper = false) {
   typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
   typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
   typedef real real2_t __attribute__((ext_vector_type(2)));
@@ -122,8 +124,10 @@ __device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned vo
     out[0] = v0;
     out[1] = v1;
 #ifndef ECCKD_DEBUG_NOSTORE   // (compile-time switch for timing experiments: arithmetic without stores)
-    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, out), rsrc, (int)voff, 0, aux);
-    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, out), rsrc, (int)voff, 0, aux);
+    if (nplanes >= 2 || !upper) {
+      if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, out), rsrc, (int)voff, 0, aux);
+      else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, out), rsrc, (int)voff, 0, aux);
+    }
 #else
     asm volatile("" :: "v"(out));
 #endif
@@ -131,10 +135,10 @@ __device__ __forceinline__ void store_pair(real *&base, long plane2, unsigned vo
     const int plane_bytes = (int)((plane2 / 2) * (long)sizeof(real));
     if constexpr (sizeof(real) == 8) {
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v0), rsrc, (int)coff, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v1), rsrc, (int)coff, plane_bytes, 0);
+      if (nplanes >= 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v1), rsrc, (int)coff, plane_bytes, 0);
     } else {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rsrc, (int)coff, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rsrc, (int)coff, plane_bytes, 0);
+      if (nplanes >= 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rsrc, (int)coff, plane_bytes, 0);
     }
   }
   base += plane2;
