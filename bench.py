@@ -710,6 +710,9 @@ def main():
             out["configs_2"] = {k2: sw[k2] for k2 in ("value", "unit", "ms_per_step", "roofline", "roofline_fp64_valu", "roofline_pipeline",
                                                       "kernels", "fused_sw", "check_max_abs_flux_diff_vs_oracle_Wm2")}
             out["configs_2"]["workload"] = sw["config"]["workload"]
+            sw32 = sw_measure(100000, args.steps, args.warmup, fused=False, dtype="f32")     # the same pair in single precision
+            out["configs_2"]["f32"] = {k2: sw32[k2] for k2 in ("value", "unit", "ms_per_step", "roofline_pipeline", "kernels",
+                                                               "check_max_abs_flux_diff_vs_oracle_Wm2")}
             torch.cuda.empty_cache()
             out["configs_4"] = {dt4: lw_measure(pkg, LW_FILE.replace("fsck-tol0.0161", "rrtmgp-tol0.061"), 1000000, dt4, args.steps,
                                                 args.warmup, local_rank) for dt4 in ("f64", "f32")}
@@ -755,11 +758,11 @@ def main():
 
 
 def main_sw(args):
-    print(json.dumps(sw_measure(args.ncol, args.steps, args.warmup, args.solver_option, fused=not args.no_side)), flush=True)
+    print(json.dumps(sw_measure(args.ncol, args.steps, args.warmup, args.solver_option, fused=not args.no_side, dtype=args.dtype)), flush=True)
 
 
-def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
-    """Secondary line: SW wide-tol0.05 (27 g-points), gas_optics (tau, ssa, g) + rte_sw two-stream, fp64,
+def sw_measure(ncol, steps, warmup, solver_option=(), fused=True, dtype="f64"):
+    """Secondary line: SW wide-tol0.05 (27 g-points), gas_optics (tau, ssa, g) + rte_sw two-stream, fp64 (or fp32),
     single GPU.  Algorithmic bytes: tau, ssa, g written once and read once = 48 B/cell (+ per-column terms)."""
     import types
     args = types.SimpleNamespace(ncol=ncol, steps=steps, warmup=warmup, solver_option=list(solver_option))
@@ -778,7 +781,9 @@ def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
     if err:
         raise SystemExit(err)
     ng, ncol, nlay = k.get_ngpt(), args.ncol, NLAY
-    f64 = dict(dtype=torch.float64, device=dev)
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    esz = 4 if dtype == "f32" else 8
+    f64 = dict(dtype=tdt, device=dev)      # (the working precision of this run)
     plev = torch.empty((nlay + 1, ncol), **f64)
     tlay = torch.empty((nlay, ncol), **f64)
     h2o = torch.empty((nlay, ncol), **f64)
@@ -788,9 +793,9 @@ def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
         n = min(100000, ncol - c0)
         cols = synthetic.columns(c0, n, k.get_press_min(), shortwave=True)
         for dst, key in ((plev, "plev"), (tlay, "tlay"), (h2o, "h2o"), (o3, "o3")):
-            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+            dst[:, c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
         for key, dst in percol.items():
-            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev)
+            dst[c0:c0 + n] = torch.from_numpy(cols[key]).to(dev).to(tdt)
     names = ["co2", "ch4", "n2o", "o2", "h2o", "o3"]
     gc = pkg.GasConcs(names)
     for name in names:
@@ -832,11 +837,11 @@ def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
     kern = {names_b.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode(): ms[i] / max(cnt[i], 1) for i in range(nk)}
     cells = ncol * nlay * ng
     ms_per_step = elapsed / args.steps * 1e3
-    alg = 48.0 * cells + 8.0 * ncol * ((nlay + 1) + 3 * nlay + 5 + 2 * ng + 2 * (nlay + 1))
+    alg = (48.0 * cells + 8.0 * ncol * ((nlay + 1) + 3 * nlay + 5 + 2 * ng + 2 * (nlay + 1))) * esz / 8
     # per kernel: gas optics writes tau, ssa, g (24 B/cell) + toa_src; the solver reads them
-    # (24 B/cell) + toa, mu0, albedos and writes 2 x 61 fluxes.  Its scratch ring is not algorithmic traffic.
-    alg_k = {"tau": 24.0 * cells + 8.0 * ncol * ((nlay + 1) + 3 * nlay + 5 + ng),
-             "rte_sw": 24.0 * cells + 8.0 * ncol * (ng + 3 + 2 * (nlay + 1))}
+    # (24 B/cell) + toa, mu0, albedos and writes 2 x 61 fluxes.
+    alg_k = {"tau": (24.0 * cells + 8.0 * ncol * ((nlay + 1) + 3 * nlay + 5 + ng)) * esz / 8,
+             "rte_sw": (24.0 * cells + 8.0 * ncol * (ng + 3 + 2 * (nlay + 1))) * esz / 8}
     kernels = {n: {"avg_ms": v, "alg_bytes_per_launch": alg_k.get(n), "GBps": alg_k[n] / (v * 1e-3) / 1e9 if n in alg_k and v > 0 else None}
                for n, v in kern.items()}
     kern = {n: v for n, v in kern.items() if n in alg_k}
@@ -871,7 +876,7 @@ def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
                 "max_abs_flux_diff_vs_api_path_Wm2": max(float((fl.flux_up - ref_up).abs().max()), float((fl.flux_dn - ref_dn).abs().max())),
                 "note": "ecckd_sw_fluxes: gas optics writes the total optical depth only, the solver derives ssa, g = 0 and the "
                         "incoming beam from plev and the model's tables (src/gas_optics_ecckd.f90:455-472); same inputs, same fluxes"}
-    ctr, csrc = committed_counters("r03_pmc_sw.json", dom, ncol)
+    ctr, csrc = committed_counters("r03_pmc_sw.json", dom, ncol) if dtype == "f64" else (None, "counter passes were taken in fp64 only")
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (kernels[dom]["GBps"] or 0.0) / HBM_PEAK_GBS,
                 "traffic": ctr.get("hbm_bytes_per_launch") if ctr else None, "traffic_source": csrc,
@@ -900,14 +905,16 @@ def sw_measure(ncol, steps, warmup, solver_option=(), fused=True):
     tau, ssa, g, toa_o, _ = oracle.gas_optics_ext(m, cols["plev"], cols["tlay"], items)
     a2 = np.repeat(cols["albedo"][None], ng, 0)
     fu, fd, _ = oracle.rte_sw(tau, ssa, g, cols["mu0"], toa_o, a2, a2)
-    dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].cpu().numpy() - fu))),
-                float(np.max(np.abs(fl.flux_dn[:, :64].cpu().numpy() - fd))))
+    dflux = max(float(np.max(np.abs(fl.flux_up[:, :64].double().cpu().numpy() - fu))),
+                float(np.max(np.abs(fl.flux_dn[:, :64].double().cpu().numpy() - fd))))
     return ({
         "metric": "Mcol*lay*gpt/s SW gas_optics+rte_sw", "value": cells * args.steps / elapsed / 1e6,
         "unit": "Mcol*lay*gpt/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "synthetic %d columns x %d layers x %d g-points, SW wide-tol0.05, gas_optics + rte_sw "
-                               "two-stream, fp64 (BASELINE configs[2])" % (ncol, nlay, ng), "solver_options": pkg.solver_options()},
+                               "two-stream, %s (BASELINE configs[2]%s)" % (ncol, nlay, ng, "fp64" if dtype == "f64" else "fp32",
+                                                                             "" if dtype == "f64" else " in single precision"),
+                   "solver_options": pkg.solver_options()},
         "roofline": roofline, "roofline_fp64_valu": valu_roof,
         "roofline_pipeline": {"bound": "hbm", "achieved": alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
