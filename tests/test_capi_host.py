@@ -172,6 +172,37 @@ def test_no_gpu_means_error_not_fallback(pkg):
     assert "no HIP device" in pkg.rte_lw(op, True, src, np.ones((ncol, 1)), fl)
 
 
+def test_round3_entry_points_without_a_gpu(pkg):
+    """The entry points and switches added in round 3 on a host-only model / without a GPU: the fused shortwave path and the
+    single-precision shortwave pair fail loudly (no CPU fallback), the new options check their values, the tail-scratch
+    queries answer 0 where no device can be asked for its size."""
+    import torch
+    from conftest import SW_WIDE
+    k = pkg.GasOpticsEcckd()
+    assert k.load(SW_WIDE, device=-1) == ""
+    nlay, ncol, ng = 60, 4, k.get_ngpt()
+    gc = pkg.GasConcs(["h2o"]); gc.set_vmr("h2o", 1e-3)
+    for dt in (np.float64, np.float32):
+        fl = pkg.FluxesBroadband(np.zeros((nlay + 1, ncol), dtype=dt), np.zeros((nlay + 1, ncol), dtype=dt))
+        msg = k.sw_fluxes(np.full((nlay + 1, ncol), 1e4, dtype=dt), np.full((nlay, ncol), 250., dtype=dt), gc, True,
+                          np.full(ncol, 0.5, dtype=dt), np.full((ncol, k.get_nband()), 0.1, dtype=dt),
+                          np.full((ncol, k.get_nband()), 0.1, dtype=dt), fl)
+        assert "no CPU fallback" in msg and np.all(fl.flux_up == 0)
+        op = pkg.OpticalProps2str(); op.alloc_2str(ncol, nlay, k, like=np.empty(0, dtype=dt))
+        assert op.tau.dtype == dt
+        if not torch.cuda.is_available():
+            msg = pkg.rte_sw(op, True, np.full(ncol, 0.5, dtype=dt), np.ones((ng, ncol), dtype=dt),
+                             np.full((ncol, k.get_nband()), 0.1, dtype=dt), np.full((ncol, k.get_nband()), 0.1, dtype=dt), fl)
+            assert "no HIP device" in msg
+    for name, bad in (("gas_slab_f32", 3), ("sw_solver", 2)):
+        with pytest.raises(ValueError):
+            pkg.set_solver_option(name, bad)
+    assert pkg.get_solver_option("gas_slab_f32") == 2 and pkg.get_solver_option("sw_solver") == 0
+    assert set(("sw_solver", "gas_slab_f32")) <= set(pkg.solver_options())
+    if not torch.cuda.is_available():
+        assert pkg.rte_sw_tail_scratch_bytes(1000, 60, 27) == 0 and pkg.rte_lw_tail_scratch_bytes(100000, 60, 32) == 0
+
+
 def test_launch_plan_host_logic(pkg, oracle_mod, monkeypatch):
     """ecckd_gas_optics_plan: the host-side decisions of gas_optics (fused or not, slab rows, Planck
     window, pass splitting, grid) on host-only models -- no GPU, nothing launched."""

@@ -505,3 +505,41 @@ def test_fused_lw_path_with_a_64_g_point_model(pkg, gpu, oracle_mod):
     assert k.lw_fluxes(plev, tlay, tsfc, tlev, gc, True, emis, f2) == ""
     assert float((fl.flux_up - f2.flux_up).abs().max()) < FLUX_ATOL and float((fl.flux_dn - f2.flux_dn).abs().max()) < FLUX_ATOL
     assert float(fl.flux_up.min()) > 0
+
+
+def test_tail_scratch_size_queries_and_a_caller_owned_block(pkg, gpu):
+    """ecckd_rte_sw_tail_scratch_bytes / ecckd_rte_lw_tail_scratch_bytes say what the optional tail splits of a
+    call would take; a caller-owned block of exactly that size serves the call (captured in a graph without a warm-up),
+    one that is a byte short makes the split step aside -- the same fluxes either way."""
+    import torch
+    rng = np.random.default_rng(17)
+    ncol, nlay, ng = 1000, 60, 9
+    need = pkg.rte_sw_tail_scratch_bytes(ncol, nlay, ng)
+    assert need == 8 * 3 * (nlay + 1) * 64 * 16 * ng                       # 16 tiles, one unit per (tile, g-point)
+    assert pkg.rte_sw_tail_scratch_bytes(256 * 64, nlay, ng) == 0           # whole rounds only: nothing to split
+    assert pkg.rte_lw_tail_scratch_bytes(100000, 60, 32) > 0 and pkg.rte_lw_tail_scratch_bytes(1024 * 32, 60, 32) == 0
+    pkg.set_solver_option("sw_tail_split", 0)
+    assert pkg.rte_sw_tail_scratch_bytes(ncol, nlay, ng) == 0
+    pkg.set_solver_option("sw_tail_split", 1)
+    inp = sw_inputs(rng, ncol, nlay, ng)
+    ref = run_sw(pkg, gpu, inp, True)
+    tau, ssa, g, mu0, toa, albd, albf, b2g = inp
+    t = T(gpu)
+    op = pkg.OpticalProps2str(); op.tau, op.ssa, op.g = t(tau), t(ssa), t(g)
+    op.band2gpt = b2g
+    args = (t(mu0), t(toa), t(albd), t(albf))
+    for size in (need, need - 1):
+        stream = torch.cuda.Stream()
+        buf = torch.empty(size, dtype=torch.uint8, device=gpu)
+        pkg.set_stream_scratch(buf, stream=stream)
+        fl = pkg.FluxesBroadband(*(torch.zeros((nlay + 1, ncol), dtype=torch.float64, device=gpu) for _ in range(3)))
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            assert pkg.rte_sw(op, True, *args, fl) == ""
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(ref, (fl.flux_up, fl.flux_dn, fl.flux_dn_dir)):
+            assert np.array_equal(a, b.cpu().numpy())
+        pkg.set_stream_scratch(None, stream=stream)
+        del graph
