@@ -543,3 +543,26 @@ def test_tail_scratch_size_queries_and_a_caller_owned_block(pkg, gpu):
             assert np.array_equal(a, b.cpu().numpy())
         pkg.set_stream_scratch(None, stream=stream)
         del graph
+
+
+def test_bench_rccl_branch_with_one_rank(pkg, gpu, tmp_path):
+    """The RCCL branch of bench.py (init_process_group("nccl", device_id=...), barrier(device_ids=...), all_reduce(MAX),
+    all_gather on device tensors) executed for real: one rank under torch.distributed.run on the one GPU of the box.  (Two
+    ranks cannot share a device over RCCL -- the two-rank tests rehearse the rank logic over gloo.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k2: v for k2, v in os.environ.items() if k2 not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--ncol", "60000",
+           "--cpu-seconds", "0", "--no-side"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and len(d["per_rank_ms_per_step"]["ranks"]) == 1 and "REHEARSAL" not in d["config"]["parallelism"]
+    assert d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL
