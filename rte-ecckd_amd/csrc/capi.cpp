@@ -1320,6 +1320,8 @@ int ecckd_rte_sw(int device, int ncol, int nlay, int ngpt, int top_at_1, const d
   a.ncol = ncol; a.nlay = nlay; a.ng = ngpt; a.top_at_1 = top_at_1 ? 1 : 0; a.nband = nband;
   a.exact_division = g_arith.load() != 0;
   a.k_floor = g_opt.sw_k_floor.load();
+  // (fast arithmetic mode: sw_sqrt() of sw_two_stream.hpp takes normal numbers; a subnormal floor changes nothing a flux can show)
+  if (!a.exact_division && a.k_floor < 2.2250738585072014e-308) a.k_floor = 2.2250738585072014e-308;
   a.dir_clamp = g_opt.sw_dir_clamp.load();
   a.f32 = g_f32;
   if (g_sw_derive) {   // ecckd_sw_fluxes: ssa / g / toa derived inside the solver (RteSwArgs::derive)

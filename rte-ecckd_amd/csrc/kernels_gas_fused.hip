@@ -166,11 +166,14 @@ __global__ void __launch_bounds__(256) spread_probe_kernel(const real *plev, int
 // disk (widened exactly on read, mo_simple_netcdf.F90:44-142), so the slab and the Planck table can be staged as the
 // float32 they are -- half the LDS -- and widened again (v_cvt_f64_f32, exact) when they are used: the same bits.  The
 // host checks that every value is float32-representable (FusedArgs::slab32).
+#ifndef ECCKD_F64_WAVES
+#define ECCKD_F64_WAVES 2
+#endif
 #ifndef ECCKD_F32_WAVES
 #define ECCKD_F32_WAVES 2
 #endif
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
-__global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES : 2)) gas_fused_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES : ECCKD_F64_WAVES)) gas_fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   sreal *lds = reinterpret_cast<sreal *>(lds_raw);
   typedef sreal double2_t __attribute__((ext_vector_type(2)));   // (two consecutive g-points as they sit in LDS)
@@ -786,10 +789,14 @@ hipError_t launch_mode(const FusedArgs &a, size_t lds, int NBsel, bool anyclamp,
   const int ng = a.tau.ng;
   if (anyclamp && ng % 4 == 0) return launch_one<real, 4, kTauPassGases, true, true, MODE>(a, lds, s);
   if (anyclamp) return launch_one<real, 4, kTauPassGases, false, true, MODE>(a, lds, s);
+#ifndef ECCKD_FUSED_NOGC8   // (experiment: chunks of four g-points only)
   if (NBsel == 2 && ng % 8 == 0) return launch_one<real, 8, 2, true, false, MODE>(a, lds, s);
+#endif
   if (NBsel == 2 && ng % 4 == 0) return launch_one<real, 4, 2, true, false, MODE>(a, lds, s);
   if (NBsel == 2) return launch_one<real, 4, 2, false, false, MODE>(a, lds, s);
+#ifndef ECCKD_FUSED_NOGC8
   if (NBsel == 7 && ng % 8 == 0) return launch_one<real, 8, 7, true, false, MODE>(a, lds, s);
+#endif
   if (NBsel == 7 && ng % 4 == 0) return launch_one<real, 4, 7, true, false, MODE>(a, lds, s);
   if (NBsel == 5 && ng % 4 == 0) return launch_one<real, 4, 5, true, false, MODE>(a, lds, s);
   if (NBsel == 5) return launch_one<real, 4, 5, false, false, MODE>(a, lds, s);
@@ -809,6 +816,9 @@ bool slab32_applies(int mode, int ng, int nbil, bool anyclamp) {
 
 void pick_shape(int ng, int nbil, bool anyclamp, int *GC, int *NB) {
   const int nb = pick_nb(nbil);
+#ifdef ECCKD_FUSED_NOGC8
+  if (ng % 8 == 0) ng += 4;
+#endif
   if (anyclamp) { *GC = 4; *NB = kTauPassGases; }
   else if (nb == 2) { *GC = ng % 8 == 0 ? 8 : 4; *NB = 2; }
   else if (nb == 7 && ng % 8 == 0) { *GC = 8; *NB = 7; }

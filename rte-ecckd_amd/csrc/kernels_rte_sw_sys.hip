@@ -40,6 +40,18 @@ constexpr int kSysMaxLay = kSysWaves * kSysLPW;
 #define ECCKD_SYS_FMA_CHAIN 1
 #endif
 constexpr bool kSysFmaChain = ECCKD_SYS_FMA_CHAIN != 0;
+// Fast arithmetic mode, what a wave does while it holds the token (see the sweeps below):
+//   ECCKD_SYS_PROJ  U: the pair handed upwards comes from a division-free (projective) form of the adding recurrence -- two
+//                   dependent operations per layer instead of six -- and the wave's own per-layer values, which only its D
+//                   needs, are computed after the token has moved on;
+//   ECCKD_SYS_DPRE  D: everything that does not depend on the incoming pair is multiplied out before the token arrives
+//                   (direct-beam transmittances as prefix products): one dependent FMA per layer on the way to the hand-off.
+#ifndef ECCKD_SYS_PROJ
+#define ECCKD_SYS_PROJ 1
+#endif
+#ifndef ECCKD_SYS_DPRE
+#define ECCKD_SYS_DPRE 1
+#endif
 constexpr int kSysSpinLimit = 1 << 22;   // polls of a flag before the block gives up (a lost hand-off never hangs the GPU)
 
 #ifdef ECCKD_SYS_TIMING   // (variant build only: s_memtime stamps of one g-point step of block 0, read back by tools/sys_timing.py)
@@ -112,15 +124,78 @@ __device__ __forceinline__ void publish(int *flag, int seq) {
 #endif
 }
 
-// 1/x for the adding recurrence of the fast arithmetic mode: hardware reciprocal (relative error <= 2^-23 in fp64) and ONE
-// third-order step, r = r0 + r0*(e + e*e), e = 1 - x*r0: error e^3 ~ 2^-69, i.e. the correctly rounded reciprocal up to
-// the last bit -- three dependent operations behind the v_rcp instead of the four of two Newton steps (rcp<true>): the
-// reciprocal sits on the critical path of the block once per layer.
-__device__ __forceinline__ double rcp_chain(double x) {
-  const double r0 = __builtin_amdgcn_rcp(x);
-  const double e = fma(-x, r0, 1.);
-  return fma(fma(e, e, e), r0, r0);
+// The token of a sweep: the pair of values of every lane in the receiving wave's LDS slot (one 16-byte word per lane in
+// fp64), then the slot's flag word with the sequence number of the step.  ECCKD_SYS_HANDOFF:
+//   0  (until late in round 3) release store of the flag behind an s_waitcnt on the data; the receiver polls the flag
+//      with a nap between polls and reads its pair afterwards: three LDS round trips between "the sender is done" and
+//      "the receiver computes" -- measured ~500 clocks per hand-off, 24 hand-offs per g-point step, half the step;
+//   1  the LDS executes the DS instructions of a wave in order, so (i) the sender issues data and flag back to back and
+//      (ii) the receiver asks for flag AND data in one round (flag first): a flag that reads `seq` vouches for the data read
+//      behind it.  So that eleven waiting waves do not crowd the LDS queue with 1 KiB polls (the sentinel experiment of
+//      §5.4), a wave first naps on the flag of the wave the token comes FROM -- only the next wave in line polls its slot.
+#ifndef ECCKD_SYS_HANDOFF
+#define ECCKD_SYS_HANDOFF 1
+#endif
+#ifndef ECCKD_SYS_SLEEP2
+#define ECCKD_SYS_SLEEP2 0   // nap between the polls of the next wave in line (x 64 clocks; 0: none)
+#endif
+template <typename real> struct SysPair { typedef real type __attribute__((ext_vector_type(2))); };
+
+// near: flag word of the wave the token comes from (nullptr: that wave starts the sweep), flag / slot: this wave's own.
+template <typename real>
+__device__ __forceinline__ typename SysPair<real>::type take_token(int *near, int *flag, const real *slot, int seq, int *abort_) {
+  typedef typename SysPair<real>::type pair_t;
+  typedef __attribute__((address_space(3))) const volatile pair_t lds_pair;
+  typedef __attribute__((address_space(3))) const volatile int lds_int;
+#if ECCKD_SYS_HANDOFF == 0
+  (void)near;
+  wait_flag(flag, seq, abort_);
+  return *(lds_pair *)slot;
+#else
+#ifdef ECCKD_SYS_DEBUG_NOWAIT
+  return *(lds_pair *)slot;
+#endif
+  if (near) wait_flag(near, seq, abort_);
+  int spins = 0;
+  pair_t v;
+  for (;;) {
+    const int f = *(lds_int *)flag;   // (volatile: the two reads stay in this order, one s_waitcnt behind both)
+    v = *(lds_pair *)slot;
+    if (__builtin_amdgcn_readfirstlane(f) == seq) break;
+#if ECCKD_SYS_SLEEP2
+    __builtin_amdgcn_s_sleep(ECCKD_SYS_SLEEP2);
+#endif
+    if ((++spins & 255) == 0) {
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+      if (spins > kSysSpinLimit) {
+        __hip_atomic_store(abort_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return v;
+#endif
 }
+template <typename real>
+__device__ __forceinline__ void give_token(int *flag, real *slot, real a, real b, int seq) {
+  typedef typename SysPair<real>::type pair_t;
+  typedef __attribute__((address_space(3))) volatile pair_t lds_pair;
+  typedef __attribute__((address_space(3))) volatile int lds_int;
+  pair_t v;
+  v[0] = a; v[1] = b;
+  *(lds_pair *)slot = v;
+#if ECCKD_SYS_HANDOFF == 0
+  publish(flag, seq);
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  *(lds_int *)flag = seq;
+#endif
+}
+
+// 1/x for the adding recurrence of the fast arithmetic mode: rcp<true> of sw_two_stream.hpp (hardware reciprocal and one
+// third-order step: three dependent operations behind the v_rcp).
+__device__ __forceinline__ double rcp_chain(double x) { return rcp<true>(x); }
 __device__ __forceinline__ float rcp_chain(float x) { return rcp<true>(x); }
 
 // real: storage and arithmetic type.  FAST / CLAMP: as rte_sw_kernel.  DERIVE: fused shortwave path (RteSwArgs::derive).
@@ -150,8 +225,9 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
   if (w >= nwa) return;                             // (no barrier below this line)
   const bool top_wave = w == 0, bottom_wave = w == nwa - 1;
   const long lay0 = a.top_at_1 ? 0 : nlay - 1, lev0 = a.top_at_1 ? 0 : nlay, lstep = a.top_at_1 ? 1 : -1;
-  real *hu_alb = hand + ((long)w * 4 + 0) * 64 + lane;
-  real *hd_fdn = hand + ((long)w * 4 + 2) * 64 + lane;
+  // hand-off slots: [wave][U, D][lane] pairs
+  real *slot_u = hand + (((long)w * 2 + 0) * 64 + lane) * 2, *slot_d = hand + (((long)w * 2 + 1) * 64 + lane) * 2;
+  real *slot_u_above = slot_u - 4 * 64, *slot_d_below = slot_d + 4 * 64;
   const real k_floor = (real)a.k_floor;
   const real gw = (real)a.gw;
   double *my_up = acc_up + s0 * 64 + lane, *my_dn = acc_dn + s0 * 64 + lane, *my_dir = acc_dir + s0 * 64 + lane;
@@ -293,17 +369,47 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
         // ---- U: adding, bottom -> top.  The source is carried normalised by the direct beam at its own level (the
         // beam is only known on the way down): src(l) = nsrc(l) * F_dir(l), F_dir(l+1) = Tnoscat(l) * F_dir(l) ----
         SYS_STAMP(2);
-        if (!bottom_wave) wait_flag(&ctl->flag_u[w], seq, &ctl->abort_);
+        typename SysPair<real>::type tok;
+        tok[0] = pb0; tok[1] = pb1;
+        if (!bottom_wave) tok = take_token<real>(w + 1 < nwa - 1 ? &ctl->flag_u[w + 1] : nullptr, &ctl->flag_u[w], slot_u, seq, &ctl->abort_);
         SYS_STAMP(3);
 #ifndef ECCKD_SYS_NOPRIO
         // the sweeps are the critical path of the block: the wave that holds the token issues ahead of the waves of
         // its SIMD that are still computing coefficients
         __builtin_amdgcn_s_setprio(3);
 #endif
-        const real h_alb = hu_alb[0], h_src = hu_alb[64];   // (read by the bottom wave too, and ignored: no pointer select)
-        albedo = bottom_wave ? pb0 : h_alb;
-        nsrc = bottom_wave ? pb1 : h_src;
+        albedo = tok[0];
+        nsrc = tok[1];
         if (bottom_wave && g + 1 < g_end) load_albedos(g + 1);
+        constexpr bool kProj = FAST && kSysFmaChain && ECCKD_SYS_PROJ != 0;
+        constexpr bool kDpre = FAST && kSysFmaChain && ECCKD_SYS_DPRE != 0;
+        if constexpr (kProj) {
+          // The pair for the wave above, ahead of everything else.  With albedo = p/q and nsrc = s/q the recurrence
+          //   albedo' = Rdif + Tdif^2 albedo / (1 - Rdif albedo),  nsrc' = Rdir + Tdif (nsrc Tn + albedo Tdir) / (1 - Rdif albedo)
+          // is linear in (p, q, s):  q' = q - Rdif p,  p' = Rdif q' + Tdif^2 p,  s' = Rdir q' + Tdif Tn s + Tdif Tdir p,
+          // two dependent operations per layer (p -> q' -> p'; s trails by a constant) and ONE reciprocal per wave instead
+          // of one per layer.  q' / q = 1 - Rdif albedo lies in (0, 1]: five layers cannot underflow, and the pair is
+          // handed on normalised (q = 1).  The values differ from the per-layer form below in the last bits only.
+          if (!top_wave) {
+            real p = albedo, q = real(1), sN = nsrc;
+#pragma unroll
+            for (int l = LPW - 1; l >= 0; --l) {
+              if (FULL || l < nl) {
+                const real Rdif = st[l][0], Tdif = st[l][1], Rdir = st[l][2], Tdir = st[l][3], Tn = st[l][4];
+                const real qn = fma(-Rdif, p, q);
+                sN = fma(Tdif * Tn, sN, fma(Rdir, qn, Tdif * (Tdir * p)));
+                p = fma(Rdif, qn, (Tdif * Tdif) * p);
+                q = qn;
+              }
+            }
+            const real rq = rcp_chain(q);
+            give_token<real>(&ctl->flag_u[w - 1], slot_u_above, p * rq, sN * rq, seq);
+            SYS_STAMP(7);
+#ifndef ECCKD_SYS_NOPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+          }
+        }
         real dn[LPW];
 #pragma unroll
         for (int l = LPW - 1; l >= 0; --l) {
@@ -335,17 +441,35 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
             st[l][1] = A;
           }
         }
-        if (!top_wave) {
-          hu_alb[-4 * 64] = albedo;   // slot of the wave above
-          hu_alb[-3 * 64] = nsrc;
-          publish(&ctl->flag_u[w - 1], seq);
+        if (!kProj && !top_wave) {
+          give_token<real>(&ctl->flag_u[w - 1], slot_u_above, albedo, nsrc, seq);
 #ifndef ECCKD_SYS_NOPRIO
           __builtin_amdgcn_s_setprio(0);   // (waiting for the token to come back down)
 #endif
         }
+#ifndef ECCKD_SYS_NOPRIO
+        if (kProj && top_wave) __builtin_amdgcn_s_setprio(0);
+#endif
+        if constexpr (kDpre) {
+          // D-form of a layer: Y, A, albedo below, P, -, normalised source below, with P(l) = product of the direct-beam
+          // transmittances of this wave's layers above and including l, and Y = B nsrc_below P(l) + C P(l-1): the diffuse
+          // flux below layer l is A fdn + Y fdir_in, the beam P(l) fdir_in -- fdir_in the beam that arrives with the token.
+          real Pacc = real(1);
 #pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-          if (FULL || l < nl) { st[l][0] = st[l][0] * dn[l]; st[l][3] = st[l][3] * dn[l]; }
+          for (int l = 0; l < LPW; ++l) {
+            if (FULL || l < nl) {
+              const real B = st[l][0] * dn[l], C = st[l][3] * dn[l];
+              const real Pn = Pacc * st[l][4];
+              st[l][0] = fma(B * st[l][5], Pn, C * Pacc);
+              st[l][3] = Pn;
+              Pacc = Pn;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int l = 0; l < LPW; ++l) {
+            if (FULL || l < nl) { st[l][0] = st[l][0] * dn[l]; st[l][3] = st[l][3] * dn[l]; }
+          }
         }
       }
       // ---- the lower waves: coefficients of the next g-point while the token is away ----
@@ -359,8 +483,10 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
       if (step) {
         // ---- D: direct beam and fluxes, top -> bottom (Eq 12, 13) ----
         SYS_STAMP(4);
-        if (!top_wave) wait_flag(&ctl->flag_d[w], seq, &ctl->abort_);
-        const real h_fdn = hd_fdn[0], h_dir = hd_fdn[64];
+        typename SysPair<real>::type tokd;
+        tokd[0] = real(0); tokd[1] = real(0);
+        if (!top_wave) tokd = take_token<real>(w > 1 ? &ctl->flag_d[w - 1] : nullptr, &ctl->flag_d[w], slot_d, seq, &ctl->abort_);
+        const real h_fdn = tokd[0], h_dir = tokd[1];
         SYS_STAMP(5);
 #ifndef ECCKD_SYS_NOPRIO
         __builtin_amdgcn_s_setprio(3);
@@ -370,9 +496,37 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
         if (top_wave && g + 1 < g_end) load_toa(g + 1);
         const real fup0 = fdn * albedo + nsrc * fdir, fdn0 = fdn + fdir, fdir0 = fdir;   // level 0 (top wave)
         real fu[LPW], fd[LPW], fr[LPW];
+        constexpr bool kDpreD = FAST && kSysFmaChain && ECCKD_SYS_DPRE != 0;
+        if constexpr (kDpreD) {
+          const real fdir_in = fdir;
+          real Plast = real(1);
+#pragma unroll
+          for (int l = 0; l < LPW; ++l) {
+            if (FULL || l < nl) {
+              fdn = fma(st[l][1], fdn, st[l][0] * fdir_in);   // Eq 12: the one dependent operation per layer
+              fd[l] = fdn;
+              Plast = st[l][3];
+            }
+          }
+          if (!bottom_wave) {
+            give_token<real>(&ctl->flag_d[w + 1], slot_d_below, fdn, Plast * fdir_in, seq);
+          }
+#ifndef ECCKD_SYS_NOPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+          for (int l = 0; l < LPW; ++l) {
+            if (FULL || l < nl) {
+              const real fdir_next = st[l][3] * fdir_in;
+              fu[l] = fma(fd[l], st[l][2], st[l][5] * fdir_next);   // Eq 13
+              fd[l] = fd[l] + fdir_next;
+              fr[l] = fdir_next;
+            }
+          }
+        }
 #pragma unroll
         for (int l = 0; l < LPW; ++l) {
-          if (FULL || l < nl) {
+          if (!kDpreD && (FULL || l < nl)) {
             const real B = st[l][0], A = st[l][1], alb_next = st[l][2], C = st[l][3], Tn = st[l][4], nsrc_next = st[l][5];
             const real fdir_next = Tn * fdir;
             const real src_next = nsrc_next * fdir_next;
@@ -390,13 +544,11 @@ __global__ void __launch_bounds__(64 * kSysWaves) rte_sw_sys_kernel(const RteSwA
             fr[l] = fdir;
           }
         }
-        if (!bottom_wave) {
-          hd_fdn[4 * 64] = fdn;       // slot of the wave below
-          hd_fdn[5 * 64] = fdir;
-          publish(&ctl->flag_d[w + 1], seq);
+        if (!kDpreD && !bottom_wave) {
+          give_token<real>(&ctl->flag_d[w + 1], slot_d_below, fdn, fdir, seq);
         }
 #ifndef ECCKD_SYS_NOPRIO
-        __builtin_amdgcn_s_setprio(0);
+        if (!kDpreD) __builtin_amdgcn_s_setprio(0);
 #endif
         // the token has moved on: now the sums (one fire-and-forget ds_add_f64 each; every lane owns its words)
         if (top_wave) {

@@ -19,6 +19,6 @@ rc = L.ecckd_debug_sys_times(buf)
 t = [[buf[w * 8 + i] for i in range(8)] for w in range(12)]
 t0 = min(x for r in t for x in r[:7] if x)
 print("rc", rc, "ticks (s_memtime, 100 MHz = 10 ns per tick)" )
-print("wave   P_start    P_end  loads_issued  U_token   U_done->D_wait  D_token   D_done")
+print("wave   P_start    P_end  loads_issued  U_token   U_done->D_wait  D_token   D_done  U_published")
 for w, r in enumerate(t):
-    print("%4d " % w + " ".join("%9d" % (x - t0) for x in r[:7]))
+    print("%4d " % w + " ".join("%9d" % (x - t0) for x in r[:8]))
