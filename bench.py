@@ -65,7 +65,7 @@ def kernel_source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rte-ecckd_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith(".hip") or f in ("kernels.hpp", "wave_pair.hpp", "sw_two_stream.hpp", "sw_two_stream_body.inc"):
+        if f.endswith(".hip") or f in ("kernels.hpp", "wave_pair.hpp", "sw_two_stream.hpp", "sw_two_stream_body.inc", "lw_layer.hpp"):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

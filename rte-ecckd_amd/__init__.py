@@ -36,7 +36,7 @@ NAME_LEN = 32
 _SOURCES = ["kernels_gas_fused.hip", "kernels_tau.hip", "kernels_planck.hip", "kernels_rte_lw.hip", "kernels_rte_lw_split.hip",
             "kernels_rte_sw.hip", "kernels_rte_sw_sys.hip", "kernels_rte_gpt.hip",
             "capi.cpp", "nc_capi.cpp", "model.cpp", "cdf1.cpp"]
-_HEADERS = ["kernels.hpp", "wave_pair.hpp", "sw_two_stream.hpp", "sw_two_stream_body.inc", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h"),
+_HEADERS = ["kernels.hpp", "wave_pair.hpp", "sw_two_stream.hpp", "sw_two_stream_body.inc", "lw_layer.hpp", "model.hpp", "cdf1.hpp", os.path.join("..", "..", "include", "ecckd_hip.h"),
             os.path.join("..", "..", "include", "ecckd_nc.h"), os.path.join("..", "..", "include", "rte_kernels_hip.h")]
 # second library: RTE-RRTMGP's kernel-level bind(C) names over the C ABI of the first (include/rte_kernels_hip.h)
 RTE_KERNELS_LIB = os.path.join(_HERE, "librte_kernels_hip.so")

@@ -37,6 +37,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "lw_layer.hpp"
 
 namespace ecckd {
 namespace {
@@ -84,9 +85,14 @@ __device__ __forceinline__ void acc_add(double *p, real v, bool owner) {
 #endif
 }
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3>
+// OFF32 (the exact-layer-count variants): the inputs of a g-point group are addressed as a wave-uniform pointer to the
+// group's first plane plus ONE 32-bit byte offset per lane, advanced by a layer per request -- the loads take the pointer in
+// SGPRs and no vector instruction builds an address (five 64-bit vector operations per layer otherwise, in a kernel that is
+// paid per instruction).  Needs GW planes to span less than 4 GiB; launch_real() falls back to 64-bit offsets beyond.
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3, bool OFF32 = false>
 __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
   static_assert(NL > 0 && !(EXACT && OVER), "unrolled layer count; overflow only in the padded form");
+  static_assert(!OFF32 || EXACT, "32-bit offsets: exact layer count only");
   constexpr int kPF = prefetch_depth(NL);
   static_assert(kPF <= NL, "prefetch ring deeper than the unrolled layer count");
   constexpr int GW = 64 / CW;
@@ -161,9 +167,26 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     // rewritten as base + s*step with 60 loop-invariant scalar offsets that spill the SGPR file.
     long qn = 0;
     const long qstep = (long)ncol * lstep;
+    typedef __attribute__((address_space(1))) const char gcchar_t;
+    typedef __attribute__((address_space(1))) const real greal_t;
+    [[maybe_unused]] unsigned vo = 0;                                           // OFF32: byte offset of this lane's next request
+    [[maybe_unused]] const unsigned vstep = (unsigned)((long)sizeof(real) * qstep);   // (wraps for bottom-up storage)
+    [[maybe_unused]] const real *tau_b = nullptr, *lay_b = nullptr, *bdn_b = nullptr, *bup_b = nullptr;   // first plane of the group
+    auto at32 = [&](const real *plane) -> real {
+      return __builtin_nontemporal_load((greal_t *)((gcchar_t *)plane + vo));
+    };
     auto pair_start = [&](int it) {
-      const int g = (it / a.nmus) * GW + gs;
+      const int gb = (it / a.nmus) * GW;
+      const int g = gb + gs;
       const int gg = g < ng ? g : ng - 1;
+      if constexpr (OFF32) {
+        const long pl = (long)ncol * nlay * gb;
+        tau_b = P(a.tau) + pl; lay_b = P(a.lay_source) + pl; bdn_b = Bdn + pl; bup_b = Bup + pl;
+        vo = (unsigned)sizeof(real) * (unsigned)(cc + (long)ncol * nlay * (gg - gb) + (long)ncol * lay0);
+        asm volatile("" : "+v"(vo));
+        if (SHARED) bup_first = at32(bup_b);
+        return;
+      }
       qn = cc + (long)ncol * nlay * gg + (long)ncol * (lay0 + lstep * nover);
       asm volatile("" : "+v"(qn));
       if (SHARED && !OVER) bup_first = __builtin_nontemporal_load(Bup + qn);
@@ -171,6 +194,15 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     // `sl` = layer being requested (compile-time in the unrolled code); in the padded variants the
     // offset stops advancing at the last real layer, so absent layers re-read it (finite data).
     auto issue = [&](int slot, int sl) {
+      if constexpr (OFF32) {
+        ptau[slot] = at32(tau_b);
+        play[slot] = at32(lay_b);
+        pbdn[slot] = at32(bdn_b);
+        if (!SHARED) pbup[slot] = at32(bup_b);
+        vo += vstep;
+        asm volatile("" : "+v"(vo));
+        return;
+      }
 #ifndef ECCKD_LW_PLAIN_LOADS   // nontemporal: read-once streams
       ptau[slot] = __builtin_nontemporal_load(P(a.tau) + qn);
       play[slot] = __builtin_nontemporal_load(P(a.lay_source) + qn);
@@ -189,7 +221,8 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
     // intensity, so the loads for layer s+kPF cannot be hoisted above layer s-1 (without this
     // the scheduler issues dozens of layers of loads up front and spills the register file).
     auto issue_after = [&](int slot, int sl, real &pin) {
-      asm volatile("" : "+v"(qn), "+v"(pin));
+      if constexpr (OFF32) asm volatile("" : "+v"(vo), "+v"(pin));
+      else asm volatile("" : "+v"(qn), "+v"(pin));
       issue(slot, sl);
     };
 
@@ -220,10 +253,10 @@ __global__ void __launch_bounds__(64) rte_lw_kernel(const RteLwArgs a) {
         const bool act = !PAD || present(s);
         if (PAD) tau = act ? tau : real(0);   // absent layer: trans = 1, both sources 0
         const real tl = tau * D;
-        const real t = exp(-tl);
+        const real t = lw_exp(-tl);
         const real omt = real(1) - t;
         // both branches of lw_source_noscat's merge() are evaluated and selected (no branch)
-        const real fact_big = omt / tl - t;
+        const real fact_big = lw_div(omt, tl) - t;
         const real fact_small = SER3 ? tl * (real(0.5) + tl * (-real(1) / real(3) + tl * (real(1) / real(8))))
                                      : tl * (real(0.5) - real(1) / real(3) * tl);
         const real fact = tl > tau_thresh ? fact_big : fact_small;
@@ -333,9 +366,9 @@ constexpr int kOverWaves = 2048;   // grid of the overflow variant (its scratch 
 constexpr int kMaxRegisterLayers = 96;   // largest unrolled variant: 2 * 96 values + ~90 working registers of 512
 constexpr int kOverCW = 16;   // 16 * (nlay + 2) * CW bytes of LDS accumulators per wave: 16 columns keep 4 waves per CU
 
-template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3>
+template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED, bool SER3, bool OFF32 = false>
 hipError_t launch_ser(const RteLwArgs &a, hipStream_t s) {
-  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER, SHARED, SER3>;
+  auto k = rte_lw_kernel<real, NL, CW, EXACT, OVER, SHARED, SER3, OFF32>;
   const size_t lds = sizeof(double) * 2 * (size_t)(a.nlay + 1 + (EXACT ? 0 : 1)) * CW;
   if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -359,6 +392,13 @@ hipError_t launch_ser(const RteLwArgs &a, hipStream_t s) {
 
 template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
+  if constexpr (EXACT) {   // 32-bit lane offsets when the planes of a g-point group span less than 4 GiB (see OFF32)
+#ifndef ECCKD_LW_NO_OFF32
+    if ((double)a.ncol * a.nlay * (64 / CW) * sizeof(real) < 4294967296.)
+      return a.series3 ? launch_ser<real, NL, CW, EXACT, OVER, SHARED, true, true>(a, s)
+                       : launch_ser<real, NL, CW, EXACT, OVER, SHARED, false, true>(a, s);
+#endif
+  }
   return a.series3 ? launch_ser<real, NL, CW, EXACT, OVER, SHARED, true>(a, s)
                    : launch_ser<real, NL, CW, EXACT, OVER, SHARED, false>(a, s);
 }

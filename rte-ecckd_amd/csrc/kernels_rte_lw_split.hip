@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "lw_layer.hpp"
 
 namespace ecckd {
 namespace {
@@ -201,9 +202,9 @@ __global__ void __launch_bounds__(64 * NW * split_groups(PLANCK), WPS) rte_lw_sp
           issue(s % kSplitPF);
         }
         const double tl = tau * D;
-        const double t = exp(-tl);
+        const double t = lw_exp(-tl);
         const double omt = 1. - t;
-        const double fact_big = omt / tl - t;
+        const double fact_big = lw_div(omt, tl) - t;
         const double fact_small = SER3 ? tl * (0.5 + tl * (-1. / 3. + tl * (1. / 8.))) : tl * (0.5 - 1. / 3. * tl);
         const double fact = tl > tau_thresh ? fact_big : fact_small;
         const double sdn = omt * bdn + 2. * fact * (lay - bdn);
