@@ -197,7 +197,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan);
 // Folds the call-constant gases of a pass into one slot (TauArgs::merge_*); rewrites nbil / bil_seq.  Returns the number
 // of gases merged (0: nothing changed).  Only for the fused kernel (the reference-order kernels take each gas alone).
 int merge_scalar_gases(TauArgs &t, int f32);
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32);
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32, int block = 0);   // block: threads per block (0: the default 512)
 int fused_planck_rows(int ng, int np, int nt, int nbil, int nv_lut, int ntp, int anyclamp, int f32);
 hipError_t launch_gas_fused(FusedArgs &a, hipStream_t s);
 hipError_t launch_planck(PlanckArgs &a, hipStream_t s);

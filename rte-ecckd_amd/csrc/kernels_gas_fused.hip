@@ -38,8 +38,15 @@ namespace {
 #ifndef ECCKD_FUSED_BLOCK
 #define ECCKD_FUSED_BLOCK 512
 #endif
-constexpr int kBlock = ECCKD_FUSED_BLOCK;
-constexpr int kWaves = kBlock / 64;
+constexpr int kBlock = ECCKD_FUSED_BLOCK;   // threads of a block = columns of a tile; the shortwave mode takes kBlockSw
+// Shortwave gas optics (no Planck items, five slots: 173 VGPRs at two waves per SIMD) fits three waves per SIMD without
+// spilling (168 VGPRs, 6 spilled outside the loops): blocks of 768 threads, 1.29 -> 1.10 ms at 1e5 columns (same box,
+// profiles/r03_ab_gas_blocks_f32.txt).  The longwave shape cannot afford the registers (102 spilled: +10 %), the tau-only
+// shape gains 3 %, single precision nothing: they keep 512.
+#ifndef ECCKD_FUSED_BLOCK_SW
+#define ECCKD_FUSED_BLOCK_SW 768
+#endif
+constexpr int kBlockSw = ECCKD_FUSED_BLOCK_SW;
 #ifndef ECCKD_FUSED_SEG
 #define ECCKD_FUSED_SEG 8
 #endif
@@ -110,11 +117,11 @@ struct FLayout {
 // ntp = Planck rows held in LDS (the whole table, or the window FusedArgs::pw).
 // Offsets are in elements of the LDS storage type; `wide` = sizeof(arithmetic type) / sizeof(storage type) (2 for the
 // fp32 image of an fp64 call): the reduction scratch holds arithmetic-type values.
-__host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp, int wide = 1) {
+__host__ __device__ inline FLayout f_layout(int ngp, int np, int nt, int nbil, int NB, int nv_lut, int R, int ntp, int wide = 1, int waves = kBlock / 64) {
   FLayout L;
   L.tb = 0;
   L.red = (np + 1) & ~1;
-  L.bil = L.red + 4 * kWaves * wide;
+  L.bil = L.red + 4 * waves * wide;
   L.SB = nbil > 0 ? row_stride(nbil * ngp) : 2;
   L.lut = L.bil + R * nt * L.SB + NB * ngp;
   L.SL = nv_lut > 0 ? row_stride(ngp) : 2;
@@ -137,6 +144,7 @@ template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(
 }
 
 enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
+constexpr int fused_block(int mode, bool f32) { return mode == MODE_SW && !f32 ? kBlockSw : kBlock; }
 
 // "gas_slab_f32" = auto.  The fp64 slab holds R = 3 pressure rows next to the Planck table, the float32 image R = 8; the
 // widening costs 9 % where 3 rows do (measured, round 3: 13.6 against 12.6 ms at 1e6 columns) and saves a factor 3.4
@@ -172,8 +180,9 @@ __global__ void __launch_bounds__(256) spread_probe_kernel(const real *plev, int
 #ifndef ECCKD_F32_WAVES
 #define ECCKD_F32_WAVES 2
 #endif
-template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
-__global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES : ECCKD_F64_WAVES)) gas_fused_kernel(const FusedArgs a) {
+template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real, int BLOCK = kBlock>
+__global__ void __launch_bounds__(BLOCK, (BLOCK > 512 ? 3 : sizeof(real) == 4 ? ECCKD_F32_WAVES : ECCKD_F64_WAVES)) gas_fused_kernel(const FusedArgs a) {
+  constexpr int kBlock = BLOCK, kWaves = BLOCK / 64;   // (this instantiation's, not the file's defaults)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   sreal *lds = reinterpret_cast<sreal *>(lds_raw);
   typedef sreal double2_t __attribute__((ext_vector_type(2)));   // (two consecutive g-points as they sit in LDS)
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES :
   const int ntp = MODE == MODE_LW ? a.ntp : 0;
   const int PW = MODE == MODE_LW ? a.pw : 0;   // Planck rows staged in LDS: ntp (whole table) or a window
   const int ngp = (ng + GC - 1) / GC * GC;
-  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, PW, WIDE);
+  const FLayout L = f_layout(ngp, np, nt, t.nbil, NB, nv_lut, R, PW, WIDE, kWaves);
   real *redd = reinterpret_cast<real *>(lds + L.red);
   // The argument structs carry `double` pointers and scalars; in the single-precision
   // instantiation the pointers address float data (host side casts) and the scalars are rounded.
@@ -769,7 +778,8 @@ __global__ void __launch_bounds__(kBlock, (sizeof(real) == 4 ? ECCKD_F32_WAVES :
 
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
 hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
-  auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE, sreal>;
+  constexpr int kBlock = fused_block(MODE, sizeof(real) == 4);
+  auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE, sreal, kBlock>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -846,7 +856,8 @@ size_t lds_budget(int f32 = 0) {
 // if it does not fit with at least `min_rows`.
 // f32: 0 double arithmetic and tables, 1 float arithmetic and tables, 2 double arithmetic over the float32 image of the
 // tables (FusedArgs::slab32).
-int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32) {
+int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, int min_rows, int anyclamp, int f32, int block) {
+  if (block <= 0) block = kBlock;
   int GC, NB;
   pick_shape(ng, nbil, anyclamp != 0, &GC, &NB);
   const int ngp = (ng + GC - 1) / GC * GC;
@@ -854,7 +865,7 @@ int fused_slab_rows(int ng, int np, int nt, int nbil, int nv_lut, int pl_rows, i
   const size_t budget = lds_budget(f32);
   int R = 0;
   for (int r = 2; r <= np; ++r) {
-    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows, f32 == 2 ? 2 : 1).total <= budget) R = r;
+    if (esz * (size_t)f_layout(ngp, np, nt, nbil, NB, nv_lut, r, pl_rows, f32 == 2 ? 2 : 1, block / 64).total <= budget) R = r;
     else break;
   }
 #ifdef ECCKD_FUSED_MAXROWS   // (experiments: cap the slab)
@@ -992,13 +1003,14 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   if (a.slab32 && !(a.f32 == 0 && slab32_applies(a.mode, t.ng, t.nbil, anyclamp) && t.merge_slot < 0)) a.slab32 = 0;
   const int store = a.f32 ? 1 : (a.slab32 ? 2 : 0);
   if (a.mode == MODE_LW && store == 2) a.pw = fused_planck_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.ntp, anyclamp, 2);
-  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, store);
+  const int block = fused_block(a.mode, a.f32 != 0);   // threads of a block = columns of a tile
+  t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, store, block);
   const size_t lds = (store ? sizeof(float) : sizeof(double)) *
-                     (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw, store == 2 ? 2 : 1).total;
+                     (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw, store == 2 ? 2 : 1, block / 64).total;
   if (lds > lds_budget(store)) return hipErrorInvalidValue;
   // one block per CU (LDS-bound): a block count that is a multiple of the 256 CUs keeps the last
   // round of blocks full
-  const long ntiles = ((long)t.ncol + kBlock - 1) / kBlock;
+  const long ntiles = ((long)t.ncol + block - 1) / block;
   long chunks = 1;
   while ((chunks * t.nlay) % 256 != 0 && chunks < 256) ++chunks;
   while (chunks * 2 * kSeg <= ntiles && chunks * t.nlay < 2048) chunks *= 2;

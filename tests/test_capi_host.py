@@ -313,10 +313,17 @@ def test_code_object_resources(pkg):
             continue
         kind, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
         seen.add(kind)
-        if kind == "gas_fused_kernel" and targs[3] == "true":
+        if kind == "gas_fused_kernel" and targs[3] == "true" and targs[7] == "512":
             # FULL: g-point count a multiple of the chunk -- both longwave tables (32, 36 g-points), 5 / 7 / 10 gas slots,
             # with or without per-g-point clamping, every mode and precision
             assert k["spill_vgpr"] == 0, name
+        if kind == "gas_fused_kernel" and targs[7] != "512":
+            # shortwave gas optics in fp64: blocks of 768 threads, three waves per SIMD under 168 VGPRs; the shape the
+            # 27-g-point file takes (5 slots, chunks of 4, ragged last chunk) spills 6 registers outside the loops
+            assert targs[5] == "2" and targs[0] == "double" and targs[7] == "768", name
+            assert kernel_resources.waves_per_simd(k) == 3 and k["spill_vgpr"] <= 32, name
+            if targs[1:5] == ["4", "5", "false", "false"]:
+                assert k["spill_vgpr"] <= 8, name
         if kind == "rte_lw_kernel" or kind == "rte_sw_kernel":
             assert k["spill_vgpr"] == 0, name
         if kind == "rte_lw_split_kernel" and targs[0] in ("10", "12") and targs[5] == "false":
@@ -325,9 +332,9 @@ def test_code_object_resources(pkg):
             assert targs[0] == "15" and targs[6] == "2" and k["spill_vgpr"] == 0, name
     assert seen == {"gas_fused_kernel", "rte_lw_kernel", "rte_lw_split_kernel", "rte_sw_kernel", "tau_kernel"}
     # the headline instantiation, over the fp64 slab and over the float32 image of the tables ("gas_slab_f32")
-    head = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, double>" in n]
+    head = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, double, 512>" in n]
     assert len(head) == 1 and head[0]["vgpr"] <= 256 and kernel_resources.waves_per_simd(head[0]) == 2
-    head32 = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, float>" in n]
+    head32 = [k for n, k in ks.items() if "gas_fused_kernel<double, 8, 7, true, false, 1, float, 512>" in n]
     assert len(head32) == 1 and head32[0]["spill_vgpr"] == 0 and kernel_resources.waves_per_simd(head32[0]) == 2
     sys_sw = [k for n, k in ks.items() if "rte_sw_sys_kernel<double, true, false, false, true>" in n]
     assert len(sys_sw) == 1 and kernel_resources.waves_per_simd(sys_sw[0]) == 3     # 12 waves per block, one block per CU

@@ -19,13 +19,13 @@ import bench  # noqa: E402
 
 
 def short(name):
-    m = re.search(r"gas_fused_kernel<(\w+), \d+, \d+, \w+, \w+, (\d)(?:, (\w+))?>", name)
+    m = re.search(r"gas_fused_kernel<(\w+), \d+, \d+, \w+, \w+, (\d)(?:, (\w+))?(?:, \d+)?>", name)
     if m:
         base = {"0": "tau", "1": "gas_lw_fused", "2": "gas_sw"}[m.group(2)]
         if m.group(1) == "double" and m.group(3) == "float":      # fp64 over the float32 image of the tables ("gas_slab_f32"):
             return base + "_slab32"                               # with the option on auto this is the launch that returns at once
         return base + ("_f32" if m.group(1) == "float" else "")
-    m = re.search(r"rte_lw_kernel<(\w+), \d+, \d+, \w+, \w+, (\w+), \w+>", name)
+    m = re.search(r"rte_lw_kernel<(\w+), \d+, \d+, \w+, \w+, (\w+), \w+(?:, \w+)?>", name)
     if m:
         return "rte_lw" + ("_f32" if m.group(1) == "float" else "") + ("_shared_levels" if m.group(2) == "true" else "")
     m = re.search(r"rte_lw_split_kernel<\d+, \d+, \d+, \w+, \w+, (\w+), \d>", name)
