@@ -38,11 +38,12 @@ namespace {
 #ifndef ECCKD_FUSED_BLOCK
 #define ECCKD_FUSED_BLOCK 512
 #endif
-constexpr int kBlock = ECCKD_FUSED_BLOCK;   // threads of a block = columns of a tile; the shortwave mode takes kBlockSw
-// Shortwave gas optics (no Planck items, five slots: 173 VGPRs at two waves per SIMD) fits three waves per SIMD without
-// spilling (168 VGPRs, 6 spilled outside the loops): blocks of 768 threads, 1.29 -> 1.10 ms at 1e5 columns (same box,
-// profiles/r03_ab_gas_blocks_f32.txt).  The longwave shape cannot afford the registers (102 spilled: +10 %), the tau-only
-// shape gains 3 %, single precision nothing: they keep 512.
+constexpr int kBlock = ECCKD_FUSED_BLOCK;   // threads of a block = columns of a tile in the longwave mode; the others take kBlockSw
+// The shortwave and tau-only modes (no Planck items: 162-185 VGPRs at two waves per SIMD) fit three waves per SIMD with few
+// or no spills (168 VGPRs; 6-28 spilled registers in fp64, outside the loops; none in single precision): blocks of 768
+// threads.  Same box, profiles/r03_ab_gas_blocks_f32.txt, r03_ab_gas_blocks2.txt: shortwave gas optics 1.29 -> 1.10 ms in
+// fp64 and 1.17 -> 0.89 ms in fp32 at 1e5 columns, tau-only 7.38 -> 7.10 ms at 1e6.  The longwave shape cannot afford the
+// registers (102 spilled: +10 %; single precision: no gain) and keeps 512.
 #ifndef ECCKD_FUSED_BLOCK_SW
 #define ECCKD_FUSED_BLOCK_SW 768
 #endif
@@ -144,7 +145,11 @@ template <typename real> __device__ __forceinline__ PPoint<real> pressure_point(
 }
 
 enum { MODE_TAU = 0, MODE_LW = 1, MODE_SW = 2 };
-constexpr int fused_block(int mode, bool f32) { return mode == MODE_SW && !f32 ? kBlockSw : kBlock; }
+#ifndef ECCKD_FUSED_BLOCK_LW_ONLY   // (A/B builds: every mode in the 512-thread blocks of the longwave mode)
+constexpr int fused_block(int mode) { return mode == MODE_LW ? kBlock : kBlockSw; }
+#else
+constexpr int fused_block(int) { return kBlock; }
+#endif
 
 // "gas_slab_f32" = auto.  The fp64 slab holds R = 3 pressure rows next to the Planck table, the float32 image R = 8; the
 // widening costs 9 % where 3 rows do (measured, round 3: 13.6 against 12.6 ms at 1e6 columns) and saves a factor 3.4
@@ -778,7 +783,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK > 512 ? 3 : sizeof(real) == 4 ? 
 
 template <typename real, int GC, int NB, bool FULL, bool ANYCLAMP, int MODE, typename sreal = real>
 hipError_t launch_one(const FusedArgs &a, size_t lds_bytes, hipStream_t s) {
-  constexpr int kBlock = fused_block(MODE, sizeof(real) == 4);
+  constexpr int kBlock = fused_block(MODE);
   auto k = gas_fused_kernel<real, GC, NB, FULL, ANYCLAMP, MODE, sreal, kBlock>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1003,7 +1008,7 @@ hipError_t prepare_gas_fused(FusedArgs &a, FusedPlan &plan) {
   if (a.slab32 && !(a.f32 == 0 && slab32_applies(a.mode, t.ng, t.nbil, anyclamp) && t.merge_slot < 0)) a.slab32 = 0;
   const int store = a.f32 ? 1 : (a.slab32 ? 2 : 0);
   if (a.mode == MODE_LW && store == 2) a.pw = fused_planck_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.ntp, anyclamp, 2);
-  const int block = fused_block(a.mode, a.f32 != 0);   // threads of a block = columns of a tile
+  const int block = fused_block(a.mode);   // threads of a block = columns of a tile
   t.R = fused_slab_rows(t.ng, t.np, t.nt, t.nbil, nv_lut, a.pw, 0, anyclamp, store, block);
   const size_t lds = (store ? sizeof(float) : sizeof(double)) *
                      (size_t)f_layout(ngp, t.np, t.nt, t.nbil, NB, nv_lut, t.R, a.pw, store == 2 ? 2 : 1, block / 64).total;

@@ -313,16 +313,20 @@ def test_code_object_resources(pkg):
             continue
         kind, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
         seen.add(kind)
+        if kind == "gas_fused_kernel" and targs[7] == "512":
+            assert targs[5] == "1", name                  # the longwave mode keeps two waves per SIMD
         if kind == "gas_fused_kernel" and targs[3] == "true" and targs[7] == "512":
             # FULL: g-point count a multiple of the chunk -- both longwave tables (32, 36 g-points), 5 / 7 / 10 gas slots,
             # with or without per-g-point clamping, every mode and precision
             assert k["spill_vgpr"] == 0, name
         if kind == "gas_fused_kernel" and targs[7] != "512":
-            # shortwave gas optics in fp64: blocks of 768 threads, three waves per SIMD under 168 VGPRs; the shape the
-            # 27-g-point file takes (5 slots, chunks of 4, ragged last chunk) spills 6 registers outside the loops
-            assert targs[5] == "2" and targs[0] == "double" and targs[7] == "768", name
+            # shortwave and tau-only modes: blocks of 768 threads, three waves per SIMD under 168 VGPRs; the shape the
+            # 27-g-point file takes (5 slots, chunks of 4, ragged last chunk) spills 6 registers outside the loops in fp64
+            assert targs[5] in ("0", "2") and targs[7] == "768", name
             assert kernel_resources.waves_per_simd(k) == 3 and k["spill_vgpr"] <= 32, name
-            if targs[1:5] == ["4", "5", "false", "false"]:
+            if targs[0] == "float" and targs[4] == "false":       # (tables without negative entries: all ecCKD files)
+                assert k["spill_vgpr"] == 0, name
+            if targs[0] == "double" and targs[1:6] == ["4", "5", "false", "false", "2"]:
                 assert k["spill_vgpr"] <= 8, name
         if kind == "rte_lw_kernel" or kind == "rte_sw_kernel":
             assert k["spill_vgpr"] == 0, name
