@@ -390,8 +390,14 @@ int ecckd_gas_optics_plan_ex(const ecckd_model_t *model, int ncol, int nlay, int
  *   1           reference order: every product and sum in the order the Fortran expressions
  *               spell, no FMA contraction, gases accumulated in gas_desc order (:370).  tau then
  *               differs from an IEEE evaluation of the reference only through the device log().
- *   The shortwave solver follows the mode too: 0 evaluates its three reciprocals per cell with
- *   v_rcp_f64 + two Newton steps (~1 ulp), 1 with IEEE division.
+ *   The shortwave solver follows the mode too.  Mode 1: IEEE division, the device library's sqrt and exp, the adding
+ *   recurrences operation by operation in the restated order.  Mode 0 (fp64): reciprocals as v_rcp_f64 + one third-order
+ *   step, sqrt and exp without the library's range handling (~1 ulp), multiply-add pairs of the recurrences fused, the
+ *   pair a wave hands upwards from a division-free form of the adding recurrence, the flux recurrence pre-multiplied --
+ *   fluxes within 1e-11 W m-2 of mode 1 (tests/test_gpu_round3.py).  Domain of mode 0: optical depths below 1e40 (beyond,
+ *   exp(-k tau) is inf or NaN where mode 1 gives 0) and "sw_k_floor" raised to the smallest normal double if it is set below.
+ *   The longwave solver is the same in both modes; its division and exp are written out (csrc/lw_layer.hpp): the division
+ *   gives the bits of `/` for optical depths x secant below 1e290, 0 instead of ~1e-300 beyond.
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_arithmetic(int mode);
 int ecckd_get_arithmetic(void);
