@@ -394,10 +394,10 @@ int ecckd_gas_optics_plan_ex(const ecckd_model_t *model, int ncol, int nlay, int
  *   recurrences operation by operation in the restated order.  Mode 0 (fp64): reciprocals as v_rcp_f64 + one third-order
  *   step, sqrt and exp without the library's range handling (~1 ulp), multiply-add pairs of the recurrences fused, the
  *   pair a wave hands upwards from a division-free form of the adding recurrence, the flux recurrence pre-multiplied --
- *   fluxes within 1e-11 W m-2 of mode 1 (tests/test_gpu_round3.py).  Domain of mode 0: optical depths below 1e40 (beyond,
- *   exp(-k tau) is inf or NaN where mode 1 gives 0) and "sw_k_floor" raised to the smallest normal double if it is set below.
+ *   fluxes within 1e-11 W m-2 of mode 1 (tests/test_gpu_round3.py: optical depths from 1e-12 to inf, NaN columns).
+ *   Mode 0 raises "sw_k_floor" to the smallest normal double if it is set below.
  *   The longwave solver is the same in both modes; its division and exp are written out (csrc/lw_layer.hpp): the division
- *   gives the bits of `/` for optical depths x secant below 1e290, 0 instead of ~1e-300 beyond.
+ *   gives the bits of `/` for optical depths x secant below 1e290 and ~1e-290 instead of less beyond (up to inf).
  * --------------------------------------------------------------------------------------- */
 int ecckd_set_arithmetic(int mode);
 int ecckd_get_arithmetic(void);

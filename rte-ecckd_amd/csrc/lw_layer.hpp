@@ -43,15 +43,18 @@ __device__ __forceinline__ double lw_exp(double x) {
 __device__ __forceinline__ float lw_exp(float x) { return expf(x); }
 
 // x / d, fp64: the instruction sequence the compiler emits for `/` (reciprocal, two Newton steps, quotient, one residual
-// correction) WITHOUT its v_div_scale / v_div_fixup frame -- 8 instructions against 11.  That frame rescales operands whose
+// correction) WITHOUT its v_div_scale / v_div_fixup frame -- 9 instructions against 11.  That frame rescales operands whose
 // quotient or reciprocal leaves the normal range; for the one division of lw_source_noscat, (1 - t) / tl with
 // tl in (tau_thresh, 1e290) and 1 - t in [tl / 2, 1], it never acts, and the quotient is the same bits as `/`
 // (tools/check_lw_div.hip).  Outside: tl <= tau_thresh selects the series (whatever this returns, NaN and inf included,
-// is dropped by the select), tl > 1e290 gives 0 where `/` gives ~1e-300 -- both vanish against the flux.
+// is dropped by the select); the divisor is bounded by 1e290, so an optical depth beyond -- up to inf -- gives ~1e-290
+// where `/` gives less: both vanish against the flux.  A NaN divisor becomes 1e290 here (v_min_f64 returns its other
+// operand) and reaches the fluxes through the series branch, which the select takes for it.
 __device__ __forceinline__ double lw_div(double x, double d) {
 #ifdef ECCKD_LW_OLD_MATH
   return x / d;
 #endif
+  d = __builtin_fmin(d, 1e290);
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.), r, r);
   r = fma(fma(-d, r, 1.), r, r);

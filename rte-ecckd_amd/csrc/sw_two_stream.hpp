@@ -53,16 +53,19 @@ template <bool FAST>
 __device__ __forceinline__ float sw_sqrt(float x) { return sqrtf(x); }
 // exp(x) for the two transmittances of a cell, exp(-k tau) and exp(-tau / mu0).  Fast arithmetic mode, fp64: the usual
 // reduction x = n ln2 + r, |r| <= ln2 / 2, and a degree-11 polynomial (1 + r + r^2 g(r), g interpolated at Chebyshev
-// nodes: <= 0.84 ulp on 4e4 random arguments against 200-bit arithmetic) -- WITHOUT the device library's selects for
-// results beyond the double range (17 instructions against 22): v_ldexp_f64 already turns n < -1074 into +0 and n > 1023
-// into inf, and n stays meaningful as long as |x| < 1e15.  Domain: |x| < ~1e40 -- beyond it the reduction leaves a
-// remainder whose powers overflow and the result is inf or NaN where exp() gives 0 (an optical depth of 1e40).  NaN stays NaN.
+// nodes: <= 0.84 ulp on 4e4 random arguments against 200-bit arithmetic).  Instead of the device library's two compares
+// and three selects for results beyond the double range, ONE compare-and-select keeps the argument above -1100
+// (v_ldexp_f64 turns n < -1074 into +0 by itself; without the bound the reduction of |x| > 1e15 leaves a remainder whose
+// powers overflow): 20 instructions against 22, any optical depth up to inf gives what exp() gives, a NaN stays a NaN
+// (the compare is false for it).  Arguments above +709 (a negative optical depth) give inf through v_ldexp_f64 up to
+// 1e15 and are not meaningful beyond.
 #ifndef ECCKD_SW_LEAN_EXP
 #define ECCKD_SW_LEAN_EXP 1
 #endif
 template <bool FAST>
 __device__ __forceinline__ double sw_exp(double x) {
   if (!FAST || !ECCKD_SW_LEAN_EXP) return exp(x);
+  x = x < -1100. ? -1100. : x;
   const double n = __builtin_rint(x * 0x1.71547652b82fep+0);   // log2(e)
   double r = fma(n, -0x1.62e42fee00000p-1, x);                // ln2, upper 32 bits: n * hi is exact
   r = fma(n, -0x1.a39ef35793c76p-33, r);                        // ln2 - hi

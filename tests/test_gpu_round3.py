@@ -566,3 +566,86 @@ def test_bench_rccl_branch_with_one_rank(pkg, gpu, tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and len(d["per_rank_ms_per_step"]["ranks"]) == 1 and "REHEARSAL" not in d["config"]["parallelism"]
     assert d["check_max_abs_flux_diff_vs_oracle_Wm2"] < FLUX_ATOL
+
+
+# ------------------------------------------------------------------------------------------------
+# late round 3: the written-out exp / sqrt / division of the solvers at the edges of their ranges
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_shortwave_solver_extreme_and_nan_columns(pkg, gpu, oracle_mod):
+    """The fast arithmetic mode evaluates sqrt and exp without the device library's range handling (sw_two_stream.hpp) and
+    hands the adding recurrence on in its projective form: optically black layers (tau 1e3 ... 1e30), nearly transparent
+    ones (1e-12), nearly conservative scattering and a grazing sun stay within the flux tolerance of the oracle; a NaN or inf
+    optical depth poisons its own column only, and the other columns keep their bits."""
+    rng = np.random.default_rng(77)
+    ncol, nlay, ng = 200, 60, 9
+    inp = list(sw_inputs(rng, ncol, nlay, ng, nband=2, g_zero=True))
+    tau, ssa, mu0 = inp[0], inp[1], inp[3]
+    tau[:, 10:13, 0] = 1.0e3
+    tau[:, 20, 1] = 1.0e30
+    tau[:, :, 2] = 1.0e-12
+    ssa[:, :, 3] = 1.0 - 1.0e-13
+    mu0[4] = 1.0e-3
+    tau[:, :, 5] = 50.0; ssa[:, :, 5] = 0.999999
+    ref = oracle_sw(oracle_mod, inp, True)
+    scale = max(1.0, float(np.max(ref[1])) / 1000.0)
+    for arith in (pkg.FAST, pkg.REFERENCE_ORDER):
+        pkg.set_arithmetic(arith)
+        out = run_sw(pkg, gpu, inp, True)
+        for a, b in zip(out, ref):
+            assert np.all(np.isfinite(a)) and np.max(np.abs(a - b)) < FLUX_ATOL * scale * 10, arith
+    pkg.set_arithmetic(pkg.FAST)
+    clean = run_sw(pkg, gpu, inp, True)
+    bad = [x.copy() for x in inp]
+    bad[0][3, 17, 7] = np.nan
+    bad[0][5, 40, 8] = np.inf
+    out = run_sw(pkg, gpu, bad, True)
+    keep = np.ones(ncol, bool); keep[[7, 8]] = False
+    for a, b in zip(out, clean):
+        assert np.array_equal(a[:, keep], b[:, keep])
+    assert np.all(np.isnan(out[0][:, 7])) and np.any(np.isnan(out[1][:, 7]))    # NaN optical depth: NaN column
+    oref = oracle_sw(oracle_mod, bad, True)
+    for a, b in zip(out, oref):                                                  # inf optical depth: what the oracle gives
+        assert np.array_equal(np.isnan(a[:, 8]), np.isnan(b[:, 8]))
+        ok = ~np.isnan(b[:, 8])
+        assert np.max(np.abs(a[ok, 8] - b[ok, 8]), initial=0.0) < FLUX_ATOL * scale * 10
+
+
+@pytest.mark.gpu
+def test_longwave_solver_extreme_and_nan_columns(pkg, gpu, oracle_mod):
+    """rte_lw divides and exponentiates with the sequences of lw_layer.hpp: optical depths from 1e-300 (series branch) over
+    the threshold of the series to 1e30 stay within the flux tolerance of the oracle; NaN / inf optical depths poison their
+    own column as the oracle's do."""
+    from test_gpu_round2 import lw_objects
+    rng = np.random.default_rng(78)
+    ncol, nlay, ng = 96, 60, 8
+    tau = rng.uniform(1e-3, 3.0, (ng, nlay, ncol))
+    lay = rng.uniform(1.0, 10.0, (ng, nlay, ncol))
+    lev = rng.uniform(1.0, 10.0, (ng, nlay + 1, ncol))
+    inc, dec = np.ascontiguousarray(lev[:, 1:, :]), np.ascontiguousarray(lev[:, :-1, :])
+    sfc = rng.uniform(1.0, 10.0, (ng, ncol))
+    emis = rng.uniform(0.9, 1.0, (1, ncol))
+    tau[:, :, 0] = 1e-300
+    tau[:, :, 1] = 1.4e-8 / 1.66          # just below / above the series threshold sqrt(eps) after the secant
+    tau[:, :, 2] = 1.6e-8 / 1.66
+    tau[:, 30, 3] = 1e30
+    tau[:, 10:20, 4] = 800.0
+    fu, fd = oracle_mod.rte_lw(tau, lay, inc, dec, np.repeat(emis, ng, 0), sfc, top_at_1=True, nmus=1)
+    t = T(gpu)
+    op, src, fl = lw_objects(pkg, gpu, tau, lay, inc, dec, sfc)
+    assert pkg.rte_lw(op, True, src, t(emis.T.copy()), fl, n_gauss_angles=1) == ""
+    gu, gd = fl.flux_up.cpu().numpy().copy(), fl.flux_dn.cpu().numpy().copy()
+    assert np.all(np.isfinite(gu)) and np.max(np.abs(gu - fu)) < FLUX_ATOL and np.max(np.abs(gd - fd)) < FLUX_ATOL
+    tau2 = tau.copy()
+    tau2[2, 5, 9] = np.nan
+    tau2[4, 50, 11] = np.inf
+    fu2, fd2 = oracle_mod.rte_lw(tau2, lay, inc, dec, np.repeat(emis, ng, 0), sfc, top_at_1=True, nmus=1)
+    op, src, fl = lw_objects(pkg, gpu, tau2, lay, inc, dec, sfc)
+    assert pkg.rte_lw(op, True, src, t(emis.T.copy()), fl, n_gauss_angles=1) == ""
+    hu, hd = fl.flux_up.cpu().numpy(), fl.flux_dn.cpu().numpy()
+    keep = np.ones(ncol, bool); keep[[9, 11]] = False
+    assert np.array_equal(hu[:, keep], gu[:, keep]) and np.array_equal(hd[:, keep], gd[:, keep])
+    for a, b in ((hu, fu2), (hd, fd2)):
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b)
+        assert np.max(np.abs(a[ok] - b[ok])) < FLUX_ATOL
