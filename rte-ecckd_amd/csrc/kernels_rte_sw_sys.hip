@@ -33,8 +33,14 @@
 namespace ecckd {
 namespace {
 
-constexpr int kSysWaves = 12;   // waves per block: three per SIMD (<= 168 VGPRs), one block per CU
-constexpr int kSysLPW = 5;      // layers per wave
+#ifndef ECCKD_SYS_WAVES
+#define ECCKD_SYS_WAVES 12
+#endif
+#ifndef ECCKD_SYS_LPW
+#define ECCKD_SYS_LPW 5
+#endif
+constexpr int kSysWaves = ECCKD_SYS_WAVES;   // waves per block: three per SIMD (<= 168 VGPRs), one block per CU
+constexpr int kSysLPW = ECCKD_SYS_LPW;       // layers per wave
 constexpr int kSysMaxLay = kSysWaves * kSysLPW;
 #ifndef ECCKD_SYS_FMA_CHAIN
 #define ECCKD_SYS_FMA_CHAIN 1
@@ -83,7 +89,7 @@ __device__ __forceinline__ void static_for_sys(F &&f) {
 // and eleven waves poll) 1.84; that with long naps ended by the producer's s_wakeup 1.87; s_sleep 0 / 1 / 2 between
 // the polls: no difference.
 #ifndef ECCKD_SYS_SLEEP
-#define ECCKD_SYS_SLEEP 1   // x 64 clocks
+#define ECCKD_SYS_SLEEP 2   // x 64 clocks
 #endif
 #ifndef ECCKD_SYS_LIGHT_FENCES
 #define ECCKD_SYS_LIGHT_FENCES 0
@@ -136,6 +142,9 @@ __device__ __forceinline__ void publish(int *flag, int seq) {
 #ifndef ECCKD_SYS_HANDOFF
 #define ECCKD_SYS_HANDOFF 1
 #endif
+#ifndef ECCKD_SYS_POLL_PRIO
+#define ECCKD_SYS_POLL_PRIO 3
+#endif
 #ifndef ECCKD_SYS_SLEEP2
 #define ECCKD_SYS_SLEEP2 0   // nap between the polls of the next wave in line (x 64 clocks; 0: none)
 #endif
@@ -156,6 +165,11 @@ __device__ __forceinline__ typename SysPair<real>::type take_token(int *near, in
   return *(lds_pair *)slot;
 #endif
   if (near) wait_flag(near, seq, abort_);
+#if ECCKD_SYS_POLL_PRIO && !defined(ECCKD_SYS_NOPRIO)
+  // the next wave in line polls at the token holder's priority: its poll is not queued behind the coefficient arithmetic
+  // of the other waves of its SIMD (-3 %; profiles/r03_ab_sw17.txt, r03_ab_sw18.txt)
+  __builtin_amdgcn_s_setprio(ECCKD_SYS_POLL_PRIO);
+#endif
   int spins = 0;
   pair_t v;
   for (;;) {
