@@ -327,7 +327,7 @@ int ecckd_sw_fluxes_f32(const ecckd_model_t *model, int ncol, int nlay, const fl
  * rte_sw instead of the ty_fluxes_broadband the reference drivers use (ecckd_rfmip_lw.F90:108-109).
  * bnd_flux_*(ncol,nlay+1,nband) = sum over the g-points of each band (one solver pass per band over its
  * contiguous g-points); flux_up / flux_dn / flux_dir (ncol,nlay+1) are optional (NULL) and hold the sum over
- * bands.  Other arguments as ecckd_rte_lw / ecckd_rte_sw; fp64. */
+ * bands.  Other arguments as ecckd_rte_lw / ecckd_rte_sw. */
 int ecckd_rte_lw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
                         const double *tau, const double *lay_source, const double *lev_source_inc,
                         const double *lev_source_dec, const double *sfc_source, int nband,
@@ -339,6 +339,15 @@ int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, 
                         const double *sfc_alb_dif, double *bnd_flux_up, double *bnd_flux_dn,
                         double *bnd_flux_dir, double *flux_up, double *flux_dn, double *flux_dir,
                         int memspace, void *stream);
+/* The same in single precision (float arrays throughout; the band sums are taken in float). */
+int ecckd_rte_lw_byband_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles, const float *tau,
+                            const float *lay_source, const float *lev_source_inc, const float *lev_source_dec,
+                            const float *sfc_source, int nband, const int *band2gpt, const float *sfc_emis,
+                            float *bnd_flux_up, float *bnd_flux_dn, float *flux_up, float *flux_dn, int memspace, void *stream);
+int ecckd_rte_sw_byband_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, const float *tau, const float *ssa,
+                            const float *g, const float *mu0, const float *toa_flux, int nband, const int *band2gpt,
+                            const float *sfc_alb_dir, const float *sfc_alb_dif, float *bnd_flux_up, float *bnd_flux_dn,
+                            float *bnd_flux_dir, float *flux_up, float *flux_dn, float *flux_dir, int memspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Device memory for host languages without a HIP binding of their own (the Fortran shim's device-resident

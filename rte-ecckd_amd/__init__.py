@@ -791,18 +791,19 @@ def rte_lw(optical_props, top_at_1, sources, sfc_emis, fluxes, n_gauss_angles=1,
     space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, fluxes.flux_up, fluxes.flux_dn])
     dev = _device_of(optical_props.tau) if device is None else device
     if isinstance(fluxes, FluxesByband):
-        if f32 or shared_levels:
-            return "rte_lw: per-band fluxes are implemented for float64 arrays and the generic solver"
+        if shared_levels:
+            return "rte_lw: per-band fluxes are implemented for the generic solver"
         space = _space_of([optical_props.tau, sources.lay_source, sfc_emis, fluxes.bnd_flux_up, fluxes.bnd_flux_dn])
-        opt = lambda a, what: _ptr(a, (nlay + 1, ncol), what) if a is not None else None
-        rc = lib().ecckd_rte_lw_byband(
-            int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), _ptr(optical_props.tau),
-            _ptr(sources.lay_source, (ng, nlay, ncol), "lay_source"),
-            _ptr(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
-            _ptr(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
-            _ptr(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
-            _ptr(sfc_emis, (ncol, nband), "sfc_emis"), _ptr(fluxes.bnd_flux_up, (nband, nlay + 1, ncol), "bnd_flux_up"),
-            _ptr(fluxes.bnd_flux_dn, (nband, nlay + 1, ncol), "bnd_flux_dn"), opt(fluxes.flux_up, "flux_up"),
+        Pb = lambda a, shape=None, what="array": _ptr(a, shape, what, f32)
+        opt = lambda a, what: Pb(a, (nlay + 1, ncol), what) if a is not None else None
+        rc = (lib().ecckd_rte_lw_byband_f32 if f32 else lib().ecckd_rte_lw_byband)(
+            int(dev), ncol, nlay, ng, int(bool(top_at_1)), int(n_gauss_angles), Pb(optical_props.tau),
+            Pb(sources.lay_source, (ng, nlay, ncol), "lay_source"),
+            Pb(sources.lev_source_inc, (ng, nlay, ncol), "lev_source_inc"),
+            Pb(sources.lev_source_dec, (ng, nlay, ncol), "lev_source_dec"),
+            Pb(sources.sfc_source, (ng, ncol), "sfc_source"), nband, C.c_void_p(b2g.ctypes.data),
+            Pb(sfc_emis, (ncol, nband), "sfc_emis"), Pb(fluxes.bnd_flux_up, (nband, nlay + 1, ncol), "bnd_flux_up"),
+            Pb(fluxes.bnd_flux_dn, (nband, nlay + 1, ncol), "bnd_flux_dn"), opt(fluxes.flux_up, "flux_up"),
             opt(fluxes.flux_dn, "flux_dn"), space, _stream(space))
         return last_error() if rc else ""
     if shared_levels and f32:
@@ -846,15 +847,17 @@ def rte_sw(optical_props, top_at_1, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, flu
     dev = _device_of(optical_props.tau) if device is None else device
     if isinstance(fluxes, FluxesByband):
         space = _space_of([optical_props.tau, mu0, toa_flux, sfc_alb_dir, sfc_alb_dif, fluxes.bnd_flux_up])
-        opt = lambda a, shape, what: _ptr(a, shape, what) if a is not None else None
-        rc = lib().ecckd_rte_sw_byband(
-            int(dev), ncol, nlay, ng, int(bool(top_at_1)), _ptr(optical_props.tau),
-            _ptr(optical_props.ssa, (ng, nlay, ncol), "ssa"), _ptr(optical_props.g, (ng, nlay, ncol), "g"),
-            _ptr(mu0, (ncol,), "mu0"), _ptr(toa_flux, (ng, ncol), "toa_flux"), nband,
-            C.c_void_p(b2g.ctypes.data), _ptr(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"),
-            _ptr(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"),
-            _ptr(fluxes.bnd_flux_up, (nband, nlay + 1, ncol), "bnd_flux_up"),
-            _ptr(fluxes.bnd_flux_dn, (nband, nlay + 1, ncol), "bnd_flux_dn"),
+        fb = _is_f32(optical_props.tau)   # float32 arrays take ecckd_rte_sw_byband_f32
+        Pb = lambda a, shape=None, what="array": _ptr(a, shape, what, fb)
+        opt = lambda a, shape, what: Pb(a, shape, what) if a is not None else None
+        rc = (lib().ecckd_rte_sw_byband_f32 if fb else lib().ecckd_rte_sw_byband)(
+            int(dev), ncol, nlay, ng, int(bool(top_at_1)), Pb(optical_props.tau),
+            Pb(optical_props.ssa, (ng, nlay, ncol), "ssa"), Pb(optical_props.g, (ng, nlay, ncol), "g"),
+            Pb(mu0, (ncol,), "mu0"), Pb(toa_flux, (ng, ncol), "toa_flux"), nband,
+            C.c_void_p(b2g.ctypes.data), Pb(sfc_alb_dir, (ncol, nband), "sfc_alb_dir"),
+            Pb(sfc_alb_dif, (ncol, nband), "sfc_alb_dif"),
+            Pb(fluxes.bnd_flux_up, (nband, nlay + 1, ncol), "bnd_flux_up"),
+            Pb(fluxes.bnd_flux_dn, (nband, nlay + 1, ncol), "bnd_flux_dn"),
             opt(fluxes.bnd_flux_dn_dir, (nband, nlay + 1, ncol), "bnd_flux_dn_dir"),
             opt(fluxes.flux_up, (nlay + 1, ncol), "flux_up"), opt(fluxes.flux_dn, (nlay + 1, ncol), "flux_dn"),
             opt(fluxes.flux_dn_dir, (nlay + 1, ncol), "flux_dn_dir"), space, _stream(space))

@@ -1831,6 +1831,16 @@ int sum_planes(const double *planes, int nplanes, size_t n, double *out, int mem
     HIPCHK(ecckd::launch_sum_planes(planes, nplanes, n, out, g_f32, static_cast<hipStream_t>(stream)));
     return 0;
   }
+  if (g_f32) {   // (the single-precision flavours: float data behind the double pointers)
+    const float *pf = reinterpret_cast<const float *>(planes);
+    float *of = reinterpret_cast<float *>(out);
+    for (size_t i = 0; i < n; ++i) {
+      float acc = 0.f;
+      for (int b = 0; b < nplanes; ++b) acc += pf[(size_t)b * n + i];
+      of[i] = acc;
+    }
+    return 0;
+  }
   for (size_t i = 0; i < n; ++i) {
     double acc = 0.;
     for (int b = 0; b < nplanes; ++b) acc += planes[(size_t)b * n + i];
@@ -1838,6 +1848,11 @@ int sum_planes(const double *planes, int nplanes, size_t n, double *out, int mem
   }
   return 0;
 }
+// p + n elements of the precision of the call (float data sits behind the double pointers of the _f32 flavours)
+inline const double *el(const double *p, size_t n) {
+  return g_f32 ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(p) + n) : p + n;
+}
+inline double *elw(double *p, size_t n) { return g_f32 ? reinterpret_cast<double *>(reinterpret_cast<float *>(p) + n) : p + n; }
 }  // namespace
 
 int ecckd_rte_lw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles,
@@ -1854,9 +1869,9 @@ int ecckd_rte_lw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, 
     const int g0 = band2gpt[2 * b] - 1, n = band2gpt[2 * b + 1] - g0;
     const int one_band[2] = {1, n};
     BandScope scope(b);
-    if (ecckd_rte_lw(device, ncol, nlay, n, top_at_1, n_gauss_angles, tau + n3 * g0, lay_source + n3 * g0,
-                     lev_source_inc + n3 * g0, lev_source_dec + n3 * g0, sfc_source + (size_t)ncol * g0, nband,
-                     one_band, sfc_emis, bnd_flux_up + n2l * b, bnd_flux_dn + n2l * b, memspace, stream))
+    if (ecckd_rte_lw(device, ncol, nlay, n, top_at_1, n_gauss_angles, el(tau, n3 * g0), el(lay_source, n3 * g0),
+                     el(lev_source_inc, n3 * g0), el(lev_source_dec, n3 * g0), el(sfc_source, (size_t)ncol * g0), nband,
+                     one_band, sfc_emis, elw(bnd_flux_up, n2l * b), elw(bnd_flux_dn, n2l * b), memspace, stream))
       return 1;
   }
   if (ncol == 0) return 0;
@@ -1880,9 +1895,9 @@ int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, 
     const int g0 = band2gpt[2 * b] - 1, n = band2gpt[2 * b + 1] - g0;
     const int one_band[2] = {1, n};
     BandScope scope(b);
-    if (ecckd_rte_sw(device, ncol, nlay, n, top_at_1, tau + n3 * g0, ssa + n3 * g0, g + n3 * g0, mu0,
-                     toa_flux + (size_t)ncol * g0, nband, one_band, sfc_alb_dir, sfc_alb_dif, bnd_flux_up + n2l * b,
-                     bnd_flux_dn + n2l * b, bnd_flux_dir ? bnd_flux_dir + n2l * b : nullptr, memspace, stream))
+    if (ecckd_rte_sw(device, ncol, nlay, n, top_at_1, el(tau, n3 * g0), el(ssa, n3 * g0), el(g, n3 * g0), mu0,
+                     el(toa_flux, (size_t)ncol * g0), nband, one_band, sfc_alb_dir, sfc_alb_dif, elw(bnd_flux_up, n2l * b),
+                     elw(bnd_flux_dn, n2l * b), bnd_flux_dir ? elw(bnd_flux_dir, n2l * b) : nullptr, memspace, stream))
       return 1;
   }
   if (ncol == 0) return 0;
@@ -1890,6 +1905,31 @@ int ecckd_rte_sw_byband(int device, int ncol, int nlay, int ngpt, int top_at_1, 
   if (flux_dn && sum_planes(bnd_flux_dn, nband, n2l, flux_dn, memspace, stream)) return 1;
   if (flux_dir && sum_planes(bnd_flux_dir, nband, n2l, flux_dir, memspace, stream)) return 1;
   return 0;
+}
+
+// Single-precision flavours of the per-band solvers (the reference is precision-generic through `wp`).
+int ecckd_rte_lw_byband_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, int n_gauss_angles, const float *tau,
+                            const float *lay_source, const float *lev_source_inc, const float *lev_source_dec,
+                            const float *sfc_source, int nband, const int *band2gpt, const float *sfc_emis,
+                            float *bnd_flux_up, float *bnd_flux_dn, float *flux_up, float *flux_dn, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_rte_lw_byband(device, ncol, nlay, ngpt, top_at_1, n_gauss_angles, c(tau), c(lay_source), c(lev_source_inc),
+                             c(lev_source_dec), c(sfc_source), nband, band2gpt, c(sfc_emis), w(bnd_flux_up), w(bnd_flux_dn),
+                             w(flux_up), w(flux_dn), memspace, stream);
+}
+
+int ecckd_rte_sw_byband_f32(int device, int ncol, int nlay, int ngpt, int top_at_1, const float *tau, const float *ssa,
+                            const float *g, const float *mu0, const float *toa_flux, int nband, const int *band2gpt,
+                            const float *sfc_alb_dir, const float *sfc_alb_dif, float *bnd_flux_up, float *bnd_flux_dn,
+                            float *bnd_flux_dir, float *flux_up, float *flux_dn, float *flux_dir, int memspace, void *stream) {
+  F32Scope scope;
+  auto c = [](const float *p) { return reinterpret_cast<const double *>(p); };
+  auto w = [](float *p) { return reinterpret_cast<double *>(p); };
+  return ecckd_rte_sw_byband(device, ncol, nlay, ngpt, top_at_1, c(tau), c(ssa), c(g), c(mu0), c(toa_flux), nband, band2gpt,
+                             c(sfc_alb_dir), c(sfc_alb_dif), w(bnd_flux_up), w(bnd_flux_dn), w(bnd_flux_dir), w(flux_up),
+                             w(flux_dn), w(flux_dir), memspace, stream);
 }
 
 }  // extern "C"
