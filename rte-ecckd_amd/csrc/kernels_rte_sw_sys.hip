@@ -52,11 +52,15 @@ constexpr bool kSysFmaChain = ECCKD_SYS_FMA_CHAIN != 0;
 //                   needs, are computed after the token has moved on;
 //   ECCKD_SYS_DPRE  D: everything that does not depend on the incoming pair is multiplied out before the token arrives
 //                   (direct-beam transmittances as prefix products): one dependent FMA per layer on the way to the hand-off.
+//                   Worth 6 % while the sweeps set the pace; with the one-round hand-off, the polling priority and the
+//                   leaner coefficients the kernel runs within 4 % of its instruction stream without the waits, and the three
+//                   extra instructions per cell cost more than the shorter D sweep returns (1.57 -> 1.54 ms without it,
+//                   profiles/r03_ab_sw20.txt, r03_ab_sw21.txt): off by default, kept as a build option.
 #ifndef ECCKD_SYS_PROJ
 #define ECCKD_SYS_PROJ 1
 #endif
 #ifndef ECCKD_SYS_DPRE
-#define ECCKD_SYS_DPRE 1
+#define ECCKD_SYS_DPRE 0
 #endif
 constexpr int kSysSpinLimit = 1 << 22;   // polls of a flag before the block gives up (a lost hand-off never hangs the GPU)
 
