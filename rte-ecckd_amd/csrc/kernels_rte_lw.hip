@@ -394,7 +394,8 @@ template <typename real, int NL, int CW, bool EXACT, bool OVER, bool SHARED>
 hipError_t launch_one(const RteLwArgs &a, hipStream_t s) {
   if constexpr (EXACT) {   // 32-bit lane offsets when the planes of a g-point group span less than 4 GiB (see OFF32)
 #ifndef ECCKD_LW_NO_OFF32
-    if ((double)a.ncol * a.nlay * (64 / CW) * sizeof(real) < 4294967296.)
+    // (ECCKD_LW_NO_OFF32 in the environment: tests run the 64-bit form, which only calls beyond 4.4e6 columns take otherwise)
+    if ((double)a.ncol * a.nlay * (64 / CW) * sizeof(real) < 4294967296. && !getenv("ECCKD_LW_NO_OFF32"))
       return a.series3 ? launch_ser<real, NL, CW, EXACT, OVER, SHARED, true, true>(a, s)
                        : launch_ser<real, NL, CW, EXACT, OVER, SHARED, false, true>(a, s);
 #endif

@@ -714,3 +714,36 @@ def test_single_precision_fluxes_byband(pkg, gpu, oracle_mod):
             assert np.max(dd) < 0.5 and np.percentile(dd.max(axis=0), 99) < 0.05
     for got, want in ((fs.flux_up, sb.flux_up), (fs.flux_dn, sb.flux_dn), (fs.flux_dn_dir, sb.flux_dn_dir)):
         assert torch.allclose(got, want, rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_at_1,f32", [(True, False), (False, False), (True, True)])
+def test_rte_lw_lane_offsets_32_and_64_bit(pkg, gpu, monkeypatch, top_at_1, f32):
+    """The 60-layer solver addresses its inputs with 32-bit lane offsets on wave-uniform plane pointers whenever two planes
+    span less than 4 GiB, and with 64-bit offsets beyond (calls of more than 4.4e6 columns, which no test can hold): the
+    environment switch forces the 64-bit form, and both give the same bits (ragged column count, both orientations, fp32)."""
+    import torch
+    from test_gpu_round2 import lw_objects
+    rng = np.random.default_rng(80)
+    ncol, nlay, ng = 1000 + 13, 60, 7
+    dt = np.float32 if f32 else np.float64
+    tau = rng.uniform(1e-3, 3.0, (ng, nlay, ncol)).astype(dt)
+    lay = rng.uniform(1.0, 10.0, (ng, nlay, ncol)).astype(dt)
+    lev = rng.uniform(1.0, 10.0, (ng, nlay + 1, ncol)).astype(dt)
+    inc, dec = np.ascontiguousarray(lev[:, 1:, :]), np.ascontiguousarray(lev[:, :-1, :])
+    sfc = rng.uniform(1.0, 10.0, (ng, ncol)).astype(dt)
+    emis = rng.uniform(0.9, 1.0, (ncol, 1)).astype(dt)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    res = []
+    for force64 in (False, True):
+        if force64:
+            monkeypatch.setenv("ECCKD_LW_NO_OFF32", "1")
+        op = pkg.OpticalProps1scl(); op.tau = tt(tau); op.band2gpt = np.array([[1, ng]], dtype=np.int32)
+        src = pkg.SourceFuncLW()
+        src.lay_source, src.lev_source_inc, src.lev_source_dec, src.sfc_source = tt(lay), tt(inc), tt(dec), tt(sfc)
+        tdt = torch.float32 if f32 else torch.float64
+        fl = pkg.FluxesBroadband(torch.zeros((nlay + 1, ncol), dtype=tdt, device=gpu), torch.zeros((nlay + 1, ncol), dtype=tdt, device=gpu))
+        assert pkg.rte_lw(op, top_at_1, src, tt(emis), fl, n_gauss_angles=2) == ""
+        res.append((fl.flux_up.cpu().numpy().copy(), fl.flux_dn.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.all(np.isfinite(res[0][0])) and float(res[0][0].max()) > 1.0
